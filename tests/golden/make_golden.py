@@ -1,0 +1,295 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE's own Python code on the CPU.
+
+Runs only in the build container (needs /root/reference; the GPU box has neither the reference nor
+this need - it reads the committed .npz files). Nothing from the reference is copied: the script
+puts /root/reference on sys.path, imports its modules unmodified and records their outputs on the
+seeded synthetic inputs of `enarf_gan_amd.synth`.
+
+Harness-side accommodations, none of which touch arithmetic on the path:
+  * modules that are not installed here and are never executed on this path (kornia, pytorch3d,
+    dnnlib, the two un-vendored StyleGAN submodules, the compiled `triplane_sampler_cuda`) are
+    pre-seeded in sys.modules as empty placeholders whose attributes raise if ever called;
+  * the reference hard-codes device="cuda" in a few tensor factories (rendering.py:41,125,194;
+    ray_sampler.py:37,56-57,65): torch.linspace / arange / ones are wrapped to drop that kwarg and
+    torch.cuda.FloatTensor is aliased to torch.FloatTensor so the same code runs on the CPU;
+  * torch.sort is wrapped to record the sorted importance-sampling `bins` (rendering.py:197), the
+    only value needed to replay a render deterministically that the reference does not expose.
+
+Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+"""
+import os
+import sys
+import types
+
+os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+sys.dont_write_bytecode = True
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+class _Absent:
+    """Placeholder for a symbol of an uninstalled, never-executed dependency."""
+
+    def __init__(self, name):
+        self._name = name
+
+    def __call__(self, *a, **k):
+        raise RuntimeError(f"{self._name} is not available in this container and must not be reached")
+
+    def __getattr__(self, item):
+        return _Absent(f"{self._name}.{item}")
+
+    def __mro_entries__(self, bases):      # allows `class X(Absent)` in never-instantiated code
+        return (object,)
+
+
+def _placeholder(name, attrs=()):
+    m = types.ModuleType(name)
+    m.__path__ = []
+    for a in attrs:
+        setattr(m, a, _Absent(f"{name}.{a}"))
+    m.__getattr__ = lambda item, _n=name: _Absent(f"{_n}.{item}")
+    sys.modules[name] = m
+    return m
+
+
+def install_placeholders():
+    _placeholder("kornia")
+    _placeholder("kornia.augmentation", ["RandomCrop"])
+    _placeholder("libraries.stylegan2_pytorch")
+    _placeholder("libraries.stylegan2_pytorch.op", ["FusedLeakyReLU", "fused_leaky_relu"])
+    _placeholder("libraries.stylegan2_pytorch.model",
+                 ["PixelNorm", "Upsample", "Blur", "ModulatedConv2d", "Generator"])
+    _placeholder("pytorch3d")
+    _placeholder("pytorch3d.renderer", ["FoVPerspectiveCameras", "PointLights", "RasterizationSettings",
+                                        "MeshRenderer", "MeshRasterizer", "HardPhongShader", "Textures",
+                                        "PerspectiveCameras", "look_at_view_transform"])
+    _placeholder("pytorch3d.structures", ["Meshes"])
+    _placeholder("dnnlib")
+    _placeholder("triplane_sampler_cuda", ["triplane_sampler_forward", "triplane_sampler_backward"])
+
+
+_SORT_LOG = []
+
+
+def redirect_cuda_factories():
+    def strip(fn):
+        def wrapped(*a, **k):
+            if k.get("device") in ("cuda", torch.device("cuda")):
+                k.pop("device")
+            return fn(*a, **k)
+        return wrapped
+    torch.linspace = strip(torch.linspace)
+    torch.arange = strip(torch.arange)
+    torch.ones = strip(torch.ones)
+    torch.cuda.FloatTensor = torch.FloatTensor
+    _sort = torch.sort
+
+    def sort(*a, **k):
+        out = _sort(*a, **k)
+        _SORT_LOG.append(out[0].detach().clone())
+        return out
+    torch.sort = sort
+
+
+class Cfg(dict):
+    """attr-dict standing in for easydict.EasyDict (not installed)."""
+    __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__
+
+
+def nerf_cfg(origin_location, Nc, Nf):
+    return Cfg(hidden_size=32, Nc=Nc, Nf=Nf, origin_location=origin_location, coordinate_scale=3,
+               render_bs=16384, no_ray_direction=True, multiply_density_with_triplane_wieght=False,
+               clamp_mask=False, constant_triplane=True, constant_trimask=False,
+               constant_trimask_lr_mul=1, deformation_field=False, selector_mlp=False,
+               no_selector=False, time_conditional=True, pose_conditional=False, mask_input=False)
+
+
+def build_reference_model(scene, Nc, Nf, style_dim):
+    from models.narf import TriPlaneNARF
+    cfg = nerf_cfg(scene["origin_location"], Nc, Nf)
+    model = TriPlaneNARF(cfg, z_dim=style_dim, num_bone=24, bone_length=True,
+                         parent=scene["parents"], num_bone_param=23, view_dependent=False)
+    model.register_canonical_pose(scene["canonical_pose"])
+    sd = {f"mlp.{k}": v for k, v in scene["mlp"].items()}
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert set(missing) <= {"tri_plane", "canonical_joints", "canonical_parent_joints",
+                            "canonical_bone_length", "canonical_pose"}, missing
+    tri = scene["tri_plane"]
+    # per-image tri-planes (GAN style): replace the producer, which is upstream of the path
+    model.tri_plane_gen = lambda z, *a, **k: tri
+    model.eval()
+    return model
+
+
+def bitmask(valid):
+    """(B,P,...) bool -> (B,...) uint32 with bit k = part k."""
+    v = valid.cpu().numpy().astype(np.uint32)
+    P = v.shape[1]
+    sh = (np.arange(P, dtype=np.uint32)).reshape((1, P) + (1,) * (v.ndim - 2))
+    return (v << sh).sum(axis=1).astype(np.uint32)
+
+
+def run_render_case(name, size, batch, Nc, Nf, origin_location, style_dim, n_keep, seed):
+    from enarf_gan_amd import synth
+    scene = synth.make_scene(size, batch, origin_location, style_dim)
+    model = build_reference_model(scene, Nc, Nf, style_dim)
+    B, n = batch, size * size
+    _SORT_LOG.clear()
+    torch.manual_seed(seed)
+    with torch.no_grad():
+        color, mask, disp = model.forward(B, scene["image_coord"], scene["pose_to_camera"],
+                                          scene["inv_intrinsics"], None, scene["z_rend"],
+                                          scene["bone_length"], Nc=Nc, Nf=Nf, return_disparity=True)
+    ts = model.temporal_state
+    # frustum taps via the reference's own function
+    from libraries.NeRF.rendering import decide_frustrum_range
+    from libraries.NARF.pose_utils import transform_pose
+    pose_p, bl_p = transform_pose(scene["pose_to_camera"], scene["bone_length"], origin_location,
+                                  scene["parents"])
+    pose_s = pose_p.clone()
+    pose_s[:, :, :3, 3] *= 3
+    dmin, dmax, rdir, rval = decide_frustrum_range(scene["image_coord"], pose_s, scene["inv_intrinsics"],
+                                                   0.3, 5, return_camera_coord=True)
+    rval = rval.reshape(B, n)
+    bins_c = _SORT_LOG[-1]                                     # (B,1,n',Nf)
+    assert bins_c.shape[-1] == Nf
+
+    def scatter(x_c, fill=0.0):
+        """(B, n', ...) compacted (only when B == 1) -> (B, n, ...)."""
+        if B != 1:
+            return x_c
+        full = torch.full((1, n) + tuple(x_c.shape[2:]), fill, dtype=x_c.dtype)
+        full[0, rval[0]] = x_c[0]
+        return full
+
+    npr = bins_c.shape[2]
+    bins = scatter(bins_c.reshape(B, npr, Nf), 0.5)
+    cden = scatter(ts["coarse_density"].reshape(B, npr, Nc))
+    fden = scatter(model.buffers_tensors["fine_density"].reshape(B, npr, Nf))
+    fdepth = scatter(ts["fine_depth"].reshape(B, npr, Nf))
+    fweights = scatter(model.buffers_tensors["fine_weights"].reshape(B, npr, Nf - 1))
+    # validity bit masks of the fine samples, from the reference's own transform
+    with torch.no_grad():
+        fp = ts["fine_points"]                                 # (B,3,n'*Nf)
+        local, canon = model.to_local_and_canonical(fp, pose_s, bl_p)
+        from libraries.NeRF.utils import in_cube
+        v = in_cube(local) * (canon.abs() < 1).all(dim=2)      # (B,P,n'*Nf)
+    fvalid = scatter(torch.from_numpy(bitmask(v).astype(np.int64)).reshape(B, npr, Nf))
+
+    # keep a deterministic subset of rays: mostly rays that hit, some that do not
+    rs = np.random.RandomState(seed)
+    keep = []
+    for b in range(B):
+        hit = np.where(rval[b].numpy())[0]
+        miss = np.where(~rval[b].numpy())[0]
+        nh = min(len(hit), int(n_keep * 0.85))
+        nm = min(len(miss), n_keep - nh)
+        sel = np.concatenate([rs.choice(hit, nh, replace=False), rs.choice(miss, nm, replace=False)])
+        keep.append(np.sort(sel))
+    m = min(len(k) for k in keep)
+    keep = np.stack([k[:m] for k in keep])                     # (B,m)
+    bi = np.arange(B)[:, None]
+
+    out = dict(
+        size=size, batch=batch, Nc=Nc, Nf=Nf, style_dim=style_dim, seed=seed,
+        origin_location=origin_location, near=float(ts["near_plane"]), far=float(ts["far_plane"]),
+        n_valid_rays=rval.sum(dim=1).numpy(),
+        ray_idx=keep.astype(np.int32),
+        ray_validity=rval.numpy()[bi, keep],
+        depth_min=dmin.reshape(B, n).numpy()[bi, keep], depth_max=dmax.reshape(B, n).numpy()[bi, keep],
+        bins=bins.numpy()[bi, keep], coarse_density=cden.numpy()[bi, keep],
+        fine_density=fden.numpy()[bi, keep], fine_depth=fdepth.numpy()[bi, keep],
+        fine_weights=fweights.numpy()[bi, keep], fine_valid=fvalid.numpy().astype(np.uint32)[bi, keep],
+        color=color.numpy().transpose(0, 2, 1)[bi, keep].transpose(0, 2, 1),
+        mask=mask.numpy()[bi, keep], disparity=disp.numpy()[bi, keep],
+        full_mask_u8_sum=int((mask.numpy() * 255).astype(np.uint8).astype(np.int64).sum()),
+    )
+    path = os.path.join(HERE, f"{name}.npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: valid rays {rval.sum().item()}/{B * n}, kept {m}/image, "
+          f"mask mean {mask.mean().item():.4f} -> {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def run_query_case(name, batch, n_points, origin_location, style_dim, seed):
+    """calc_density_and_color_from_camera_coord_v2 (models/narf.py:176) on a point cloud."""
+    from enarf_gan_amd import synth
+    from libraries.NARF.pose_utils import transform_pose
+    from libraries.NeRF.utils import in_cube
+    scene = synth.make_scene(64, batch, origin_location, style_dim)
+    model = build_reference_model(scene, 48, 64, style_dim)
+    pose_p, bl_p = transform_pose(scene["pose_to_camera"], scene["bone_length"], origin_location,
+                                  scene["parents"])
+    pose_s = pose_p.clone()
+    pose_s[:, :, :3, 3] *= 3
+    g = torch.Generator().manual_seed(seed)
+    # points scattered around randomly chosen part centres (scaled space), so many are valid
+    P = pose_s.shape[1]
+    k = torch.randint(0, P, (batch, n_points), generator=g)
+    centre = torch.gather(pose_s[:, :, :3, 3], 1, k[..., None].expand(-1, -1, 3))    # (B,N,3)
+    pts = (centre + torch.randn(batch, n_points, 3, generator=g) * 0.7).permute(0, 2, 1).contiguous()
+    model_input = {"z": None, "z_rend": scene["z_rend"], "bone_length": bl_p, "truncation_psi": 1}
+    model.buffers_tensors = {}          # render() creates this attribute lazily (rendering.py:264-265)
+    with torch.no_grad():
+        den, col = model.calc_density_and_color_from_camera_coord_v2(pts, pose_s, None, model_input)
+        local, canon = model.to_local_and_canonical(pts, pose_s, bl_p)
+        v = in_cube(local) * (canon.abs() < 1).all(dim=2)
+    w = model.temporal_state["weight"]
+    out = dict(batch=batch, n_points=n_points, origin_location=origin_location, style_dim=style_dim,
+               points=pts.numpy(), density=den.numpy(), color=col.numpy(), valid=bitmask(v),
+               weight=w.numpy(), canonical=canon.numpy()[:, :, :, :256])
+    path = os.path.join(HERE, f"{name}.npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: valid pairs {int(v.sum())}, points with any valid {int(v.any(dim=1).sum())}/{batch * n_points}"
+          f" -> {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def run_sampler_case(name, seed):
+    """sample_feature's general branch = 3 x F.grid_sample + sum (sampling.py:27-44): the arithmetic
+    the compiled triplane_sampler implements (kernel.cu:13-92)."""
+    from libraries.triplane.sampling import sample_feature
+    g = torch.Generator().manual_seed(seed)
+    B, C, H, W, n = 2, 4, 16, 24, 300
+    inp = torch.randn(B, 3 * C, H, W, generator=g)
+    pos = (torch.rand(B, 3, n, generator=g) * 2.4 - 1.2)      # some taps out of bounds
+    pos[:, :, :8] = torch.tensor([-1.0, 1.0, 0.0, -1.0 + 1 / W, 1.0 - 1 / H, 0.999, -0.999, 1.2])
+    inp_r = inp.clone().requires_grad_(True)
+    pos_r = pos.clone().requires_grad_(True)
+    out = sample_feature(inp_r, pos_r, reduction="sum")        # (B,C,n)
+    go = torch.randn(out.shape, generator=g)
+    gi, gp = torch.autograd.grad(out, (inp_r, pos_r), go)
+    path = os.path.join(HERE, f"{name}.npz")
+    np.savez_compressed(path, input=inp.numpy(), position=pos.numpy(), output=out.detach().numpy(),
+                        grad_output=go.numpy(), grad_input=gi.numpy(), grad_position=gp.numpy())
+    print(f"{name}: -> {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def main():
+    install_placeholders()
+    redirect_cuda_factories()
+    torch.set_num_threads(8)
+    run_sampler_case("sampler_b2", seed=3)
+    run_query_case("query_b2_p23", batch=2, n_points=4096, origin_location="center_fixed", style_dim=256, seed=5)
+    run_query_case("query_b1_p24", batch=1, n_points=4096, origin_location="center+head", style_dim=20, seed=6)
+    run_render_case("render_c0_64_b1", size=64, batch=1, Nc=48, Nf=32, origin_location="center_fixed",
+                    style_dim=20, n_keep=256, seed=21)
+    run_render_case("render_c1_128_b1_p23", size=128, batch=1, Nc=48, Nf=64, origin_location="center_fixed",
+                    style_dim=20, n_keep=160, seed=22)
+    run_render_case("render_c1_128_b1_p24", size=128, batch=1, Nc=48, Nf=64, origin_location="center+head",
+                    style_dim=20, n_keep=160, seed=23)
+    run_render_case("render_gan_32_b2", size=32, batch=2, Nc=48, Nf=64, origin_location="center_fixed",
+                    style_dim=256, n_keep=128, seed=24)
+
+
+if __name__ == "__main__":
+    main()
