@@ -1,0 +1,114 @@
+"""ctypes binding of libenarf_hip.so (the C ABI declared in include/enarf_hip.h).
+
+There is no CPU fallback: if the library is missing or a call fails, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libenarf_hip.so")
+
+MAX_JOINTS = 32
+MAX_PARTS = 32
+FEAT_DIM = 32
+HIDDEN = 64
+
+INTERP = {"bilinear": 0, "nearest": 1}            # cuda_extension/triplane_sampler.py:7-10
+PADDING = {"zeros": 0, "border": 1, "reflection": 2}   # :12-16
+ORIGIN = {"center": 0, "center_fixed": 1, "center+head": 2}
+MLP_MODE = {"f32": 0, "bf16x3": 1, "bf16": 2}
+
+_f32p = C.c_void_p   # device pointers travel as integers
+
+
+class PrepareArgs(C.Structure):
+    _fields_ = [
+        ("B", C.c_int), ("num_joints", C.c_int), ("origin_location", C.c_int), ("style_dim", C.c_int),
+        ("coordinate_scale", C.c_float), ("parents", C.c_int * MAX_JOINTS),
+        ("pose_to_camera", _f32p), ("bone_length", _f32p), ("canonical_bone_length", _f32p), ("z_rend", _f32p),
+        ("conv_weight", _f32p * 3), ("mod_weight", _f32p * 3), ("mod_bias", _f32p * 3), ("bias", _f32p * 3),
+        ("parts", _f32p), ("mlp_pack", _f32p),
+    ]
+
+
+class QueryArgs(C.Structure):
+    _fields_ = [
+        ("B", C.c_int), ("N", C.c_longlong), ("P", C.c_int), ("H", C.c_int), ("W", C.c_int),
+        ("mlp_mode", C.c_int), ("multiply_density_with_weight", C.c_int),
+        ("points", _f32p), ("parts", _f32p), ("canonical_pose", _f32p),
+        ("feat_cl", _f32p), ("feat_batch_stride", C.c_longlong),
+        ("mask_planes", _f32p), ("mask_batch_stride", C.c_longlong),
+        ("mlp_pack", _f32p), ("density", _f32p), ("color", _f32p), ("valid_bits", _f32p),
+        ("dbg_canonical", _f32p), ("dbg_weight", _f32p),
+    ]
+
+
+class RenderArgs(C.Structure):
+    _fields_ = [
+        ("B", C.c_int), ("n", C.c_int), ("P", C.c_int), ("Nc", C.c_int), ("Nf", C.c_int),
+        ("H", C.c_int), ("W", C.c_int), ("mlp_mode", C.c_int), ("multiply_density_with_weight", C.c_int),
+        ("drop_invalid_rays", C.c_int), ("render_scale", C.c_float), ("early_stop_eps", C.c_float),
+        ("image_coord", _f32p), ("inv_intrinsics", _f32p), ("parts", _f32p), ("canonical_pose", _f32p),
+        ("feat_cl", _f32p), ("feat_batch_stride", C.c_longlong),
+        ("mask_planes", _f32p), ("mask_batch_stride", C.c_longlong),
+        ("mlp_pack", _f32p), ("bins", _f32p), ("seed", C.c_uint64),
+        ("color", _f32p), ("mask", _f32p), ("disparity", _f32p), ("fine_weights", _f32p), ("fine_depth", _f32p),
+        ("dbg_depth_min", _f32p), ("dbg_depth_max", _f32p), ("dbg_ray_valid", _f32p),
+        ("dbg_coarse_density", _f32p), ("dbg_fine_density", _f32p), ("dbg_fine_color", _f32p),
+        ("dbg_fine_valid", _f32p), ("dbg_bins", _f32p), ("counters", _f32p),
+    ]
+
+
+# every symbol include/enarf_hip.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "enarf_abi_version": (C.c_int, []),
+    "enarf_last_error": (C.c_char_p, []),
+    "enarf_triplane_sample_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
+    "enarf_triplane_sample_fwd": (C.c_int, [_f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_longlong,
+                                            C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "enarf_triplane_sample_bwd": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                            C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "enarf_triplane_pack": (C.c_int, [_f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "enarf_mlp_pack_bytes": (C.c_size_t, []),
+    "enarf_prepare": (C.c_int, [C.POINTER(PrepareArgs), C.c_void_p]),
+    "enarf_mlp_unpack": (C.c_int, [C.c_void_p, _f32p, C.c_void_p]),
+    "enarf_query_fwd": (C.c_int, [C.POINTER(QueryArgs), C.c_void_p]),
+    "enarf_render_fwd": (C.c_int, [C.POINTER(RenderArgs), C.c_void_p]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+class EnarfHipError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load libenarf_hip.so (once). Raises if it has not been built: there is no fallback path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EnarfHipError(
+            f"{LIB_PATH} is missing: build it with `python -m enarf_gan_amd.build` (hipcc, gfx950). "
+            "enarf_gan_amd has no CPU or eager fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.enarf_abi_version() != 1:
+        raise EnarfHipError(f"libenarf_hip.so ABI {lib.enarf_abi_version()} != 1")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().enarf_last_error().decode(errors="replace")
+        if rc == -2:
+            raise NotImplementedError(f"{what}: {msg}")
+        raise EnarfHipError(f"{what} failed (code {rc}): {msg}")

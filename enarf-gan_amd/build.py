@@ -1,0 +1,55 @@
+"""Build recipe of libenarf_hip.so (hipcc, gfx950 only), in-tree under csrc/.
+
+`python -m enarf_gan_amd.build` or `build()`; `__graft_entry__.build()` calls this. The .so is
+git-ignored but travels to the GPU box with the repo snapshot.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+LIB = os.path.join(CSRC, "libenarf_hip.so")
+SOURCES = ["enarf_render.hip", "enarf_sampler.hip"]
+HEADERS = ["enarf_device.h", "enarf_query.h", "enarf_host.h", os.path.join(ROOT, "include", "enarf_hip.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
+         "-I", os.path.join(ROOT, "include"), "-I", CSRC]
+
+
+def _newer(a: str, b: str) -> bool:
+    return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
+
+
+def build(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    deps = [os.path.join(CSRC, h) if not os.path.isabs(h) else h for h in HEADERS] + [os.path.abspath(__file__)]
+    objs, jobs = [], []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(CSRC, src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or _newer(s, o) or any(_newer(d, o) for d in deps):
+            jobs.append([hipcc, *FLAGS, *extra_flags, "-c", s, "-o", o])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed:\n{' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
+        if verbose and r.stderr.strip():
+            print(r.stderr, file=sys.stderr)
+
+    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+        list(ex.map(run, jobs))
+    if jobs or force or not os.path.exists(LIB):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

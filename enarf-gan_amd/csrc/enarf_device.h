@@ -1,0 +1,204 @@
+// enarf_device.h - shared device code of libenarf_hip.so (gfx950 / CDNA4 only, wave64).
+//
+// Conventions
+//   * "exact" functions spell every 3x3 product as ((a0*b0 + a1*b1) + a2*b2) with FMA contraction
+//     switched off, the op order of oracle/enarf_oracle.py, so cube-validity masks are bit-exact.
+//   * a part frame is 16 floats: R row-major [0..9), t (already x coordinate_scale) [9..12),
+//     canonical scale [12], pad.
+//   * the MLP pack (one per image) holds the demodulated weights in MFMA A-operand order, see below.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "enarf_hip.h"
+
+namespace enarf {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kWave = 64;
+constexpr int kPartStride = 16;
+constexpr int kFeat = ENARF_FEAT_DIM;      // 32
+constexpr int kHid = ENARF_HIDDEN;         // 64
+
+// ---- MLP pack layout --------------------------------------------------------------------------
+// fp32 section (floats). The MLP is evaluated transposed, OUT^T (units x points) = W (units x in) .
+// X^T (in x points), on 16-point tiles: lane l = (j = l & 15 : point, g = l >> 4 : k-group).
+//   v_mfma_f32_16x16x4_f32: A[i = l&15][k = l>>4], B[k = l>>4][j = l&15], D[row 4g + r][col j] in reg r.
+//   layer 1, k-step s (0..7):   k-group g feeds feature channel 8g + s  (the lane's own gathered channels)
+//   layer 2/3, k-step q = 4*ob' + r': k-group g feeds hidden unit 16ob' + 4g + r' (the lane's own acc reg)
+// so no data moves between lanes from the gather through the last layer.
+constexpr int PK_W1 = 0;                      // [4 ob][8 s][64 lanes]
+constexpr int PK_W2 = PK_W1 + 4 * 8 * 64;     // [4 ob][16 q][64 lanes]
+constexpr int PK_W3 = PK_W2 + 4 * 16 * 64;    // [16 q][64 lanes], rows 4..15 zero
+constexpr int PK_B1 = PK_W3 + 16 * 64;        // [64]
+constexpr int PK_B2 = PK_B1 + 64;             // [64]
+constexpr int PK_B3 = PK_B2 + 64;             // [16], entries 4..15 zero
+constexpr int PK_F32_FLOATS = PK_B3 + 16;     // 7312 floats = 29248 B
+// bf16 section (16-bit units), v_mfma_f32_16x16x32_bf16: A[i = l&15][k = 8(l>>4) + jj], jj = 0..7.
+//   layer 1: k = feature channel 8g + jj (one k-step)
+//   layer 2/3, k-step ks (0,1): slot (g, jj) feeds hidden unit 16(2ks + (jj>>2)) + 4g + (jj&3)
+// each A operand stored twice: hi = bf16(w), lo = bf16(w - hi)
+constexpr int PKH_W1 = 0;                               // [4 ob][hi,lo][64 lanes][8]
+constexpr int PKH_W2 = PKH_W1 + 4 * 2 * 64 * 8;         // [4 ob][2 ks][hi,lo][64][8]
+constexpr int PKH_W3 = PKH_W2 + 4 * 2 * 2 * 64 * 8;     // [2 ks][hi,lo][64][8]
+constexpr int PKH_SHORTS = PKH_W3 + 2 * 2 * 64 * 8;     // 14336 shorts = 28672 B
+constexpr size_t kPackBytes = (size_t)PK_F32_FLOATS * 4 + (size_t)PKH_SHORTS * 2;   // 57920 B
+static_assert(kPackBytes % 16 == 0, "pack must stay 16-byte aligned per image");
+
+// ---- wave primitives ----------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+// inclusive prefix sum across the 64 lanes
+__device__ __forceinline__ float wave_scan_incl(float v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        float t = __shfl_up(v, o);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+// bijective XCD-aware remap: workgroups that the dispatcher deals round-robin to one XCD get a
+// contiguous range of logical tiles, so neighbouring ray tiles share that XCD's L2.
+__device__ __forceinline__ int xcd_remap(int orig, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (orig >> 3);
+}
+
+// ---- exact-order geometry -------------------------------------------------------------------------
+// local = R^T (p - t)            (models/narf.py:158-162; libraries/NeRF/utils.py:24-27)
+__device__ __forceinline__ void exact_local(const float *F, float px, float py, float pz,
+                                            float &lx, float &ly, float &lz) {
+#pragma clang fp contract(off)
+    const float d0 = px - F[9], d1 = py - F[10], d2 = pz - F[11];
+    lx = (F[0] * d0 + F[3] * d1) + F[6] * d2;
+    ly = (F[1] * d0 + F[4] * d1) + F[7] * d2;
+    lz = (F[2] * d0 + F[5] * d1) + F[8] * d2;
+}
+// canonical = Rc (local * s) + tc   (models/narf.py:165-169); C = 12 floats: Rc row-major, tc
+__device__ __forceinline__ void exact_canonical(const float *C, float s, float lx, float ly, float lz,
+                                                float &cx, float &cy, float &cz) {
+#pragma clang fp contract(off)
+    const float q0 = lx * s, q1 = ly * s, q2 = lz * s;
+    cx = ((C[0] * q0 + C[1] * q1) + C[2] * q2) + C[9];
+    cy = ((C[3] * q0 + C[4] * q1) + C[5] * q2) + C[10];
+    cz = ((C[6] * q0 + C[7] * q1) + C[8] * q2) + C[11];
+}
+__device__ __forceinline__ bool in_unit_cube_incl(float x, float y, float z) {   // utils.py:42  (<=)
+    return fabsf(x) <= 1.0f && fabsf(y) <= 1.0f && fabsf(z) <= 1.0f;
+}
+__device__ __forceinline__ bool in_unit_cube_strict(float x, float y, float z) { // narf.py:201  (<)
+    return fabsf(x) < 1.0f && fabsf(y) < 1.0f && fabsf(z) < 1.0f;
+}
+// torch.linspace's symmetric formula (ATen RangeFactories), element i of `steps`
+__device__ __forceinline__ float linspace_sym(float start, float end, int steps, int i) {
+#pragma clang fp contract(off)
+    const float step = (end - start) / (float)(steps - 1);
+    return (i < steps / 2) ? start + step * (float)i : end - step * (float)(steps - 1 - i);
+}
+// a*(1-b) + c*b with separately rounded ops (rendering.py:120-126, :198-200)
+__device__ __forceinline__ float exact_lerp(float a, float c, float b) {
+#pragma clang fp contract(off)
+    return a * (1.0f - b) + c * b;
+}
+__device__ __forceinline__ float exact_mul(float a, float b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ float exact_mid(float e1, float e0) {   // (edge[1:] + edge[:-1]) / 2
+#pragma clang fp contract(off)
+    return (e1 + e0) / 2.0f;
+}
+__device__ __forceinline__ float exact_dot3(float a0, float b0, float a1, float b1, float a2, float b2) {
+#pragma clang fp contract(off)
+    return (a0 * b0 + a1 * b1) + a2 * b2;
+}
+
+// ---- bilinear sampling (ATen grid_sampler_2d, bilinear / zeros / align_corners=False) --------------
+struct Taps {
+    int o00, o01, o10, o11;        // y*W + x of nw, ne, sw, se (clamped in-bounds)
+    float w00, w01, w10, w11;      // weights, zeroed for out-of-bounds taps
+};
+__device__ __forceinline__ Taps make_taps(float x, float y, int H, int W) {
+    Taps t;
+    float ix, iy;
+    {
+#pragma clang fp contract(off)
+        ix = ((x + 1.0f) * (float)W - 1.0f) / 2.0f;
+        iy = ((y + 1.0f) * (float)H - 1.0f) / 2.0f;
+    }
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+    const float ax1 = ix - fx, ax0 = (fx + 1.0f) - ix;
+    const float ay1 = iy - fy, ay0 = (fy + 1.0f) - iy;
+    const bool bx0 = (x0 >= 0) & (x0 < W), bx1 = (x1 >= 0) & (x1 < W);
+    const bool by0 = (y0 >= 0) & (y0 < H), by1 = (y1 >= 0) & (y1 < H);
+    const int cx0 = min(max(x0, 0), W - 1), cx1 = min(max(x1, 0), W - 1);
+    const int cy0 = min(max(y0, 0), H - 1), cy1 = min(max(y1, 0), H - 1);
+    t.o00 = cy0 * W + cx0; t.o01 = cy0 * W + cx1; t.o10 = cy1 * W + cx0; t.o11 = cy1 * W + cx1;
+    t.w00 = (bx0 & by0) ? ax0 * ay0 : 0.0f;
+    t.w01 = (bx1 & by0) ? ax1 * ay0 : 0.0f;
+    t.w10 = (bx0 & by1) ? ax0 * ay1 : 0.0f;
+    t.w11 = (bx1 & by1) ? ax1 * ay1 : 0.0f;
+    return t;
+}
+__device__ __forceinline__ float sample_scalar_plane(const float *__restrict__ plane, float x, float y,
+                                                     int H, int W) {
+    const Taps t = make_taps(x, y, H, W);
+    float acc = plane[t.o00] * t.w00;
+    acc += plane[t.o01] * t.w01;
+    acc += plane[t.o10] * t.w10;
+    acc += plane[t.o11] * t.w11;
+    return acc;
+}
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+// StyledConv activation: LeakyReLU(0.2) * sqrt(2)   (libraries/custom_stylegan2/net.py:318)
+__device__ __forceinline__ float styled_act(float v) {
+    return (v >= 0.0f ? v : 0.2f * v) * 1.41421356237309515f;
+}
+
+// ---- bf16 helpers -------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned short f32_to_bf16_rne(float f) {
+    unsigned u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);          // inputs here are finite weights / activations
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
+
+// ---- Philox4x32-10 (counter-based RNG for the importance samples) -----------------------------------
+__device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                           uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ float u32_to_unit(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }   // [0,1)
+
+}  // namespace enarf

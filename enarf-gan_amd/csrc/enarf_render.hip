@@ -1,0 +1,623 @@
+// enarf_render.hip - prepare, point-cloud query and the fused ray-march kernels + their C-ABI entry points.
+// gfx950 only. See include/enarf_hip.h for the contract and DESIGN.md for the kernel design.
+#include "enarf_query.h"
+#include "enarf_host.h"
+
+namespace enarf {
+
+// =================================================================================================
+// enarf_prepare: part frames + per-image modulated MLP weights, one workgroup per image
+// =================================================================================================
+struct PrepareParams {
+    enarf_prepare_args a;
+};
+
+__device__ __forceinline__ void pack_weight_row(float *__restrict__ pf, short *__restrict__ ph, int layer, int o,
+                                                int c, float w) {
+    // see the layout comment in enarf_device.h
+    const int ob = o >> 4, i = o & 15;
+    const unsigned short hi = f32_to_bf16_rne(w);
+    const unsigned short lo = f32_to_bf16_rne(w - bf16_to_f32(hi));
+    if (layer == 0) {
+        const int g = c >> 3, s = c & 7;
+        pf[PK_W1 + (ob * 8 + s) * 64 + g * 16 + i] = w;
+        short *h = ph + PKH_W1 + ob * 1024 + (g * 16 + i) * 8 + s;
+        h[0] = (short)hi;
+        h[512] = (short)lo;
+    } else {
+        const int obp = c >> 4, g = (c & 15) >> 2, rp = c & 3;
+        const int q = obp * 4 + rp, ks = obp >> 1, jj = (obp & 1) * 4 + rp;
+        if (layer == 1) {
+            pf[PK_W2 + (ob * 16 + q) * 64 + g * 16 + i] = w;
+            short *h = ph + PKH_W2 + (ob * 2 + ks) * 1024 + (g * 16 + i) * 8 + jj;
+            h[0] = (short)hi;
+            h[512] = (short)lo;
+        } else {
+            pf[PK_W3 + q * 64 + g * 16 + i] = w;
+            short *h = ph + PKH_W3 + ks * 1024 + (g * 16 + i) * 8 + jj;
+            h[0] = (short)hi;
+            h[512] = (short)lo;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void prepare_kernel(const PrepareParams prm) {
+    const enarf_prepare_args &a = prm.a;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int J = a.num_joints;
+    const int P = (a.origin_location == ENARF_ORIGIN_CENTER_HEAD) ? J : J - 1;
+    __shared__ float s_style[kHid];
+    __shared__ float s_w[kHid * kHid];
+
+    // ---- part frames (pose_utils.py:129-148, rendering.py:258-260, narf.py:165)
+    if (a.parts && tid < P) {
+        const float *pose = a.pose_to_camera + (size_t)b * J * 16;
+        float *out = a.parts + ((size_t)b * P + tid) * kPartStride;
+        float R[9], t[3], bl;
+        if (tid < J - 1) {
+            const int j = tid + 1, p = a.parents[j];
+            const int rs = (a.origin_location == ENARF_ORIGIN_CENTER) ? j : p;
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) R[r * 3 + c] = pose[rs * 16 + r * 4 + c];
+            for (int r = 0; r < 3; ++r) {
+#pragma clang fp contract(off)
+                t[r] = ((pose[j * 16 + r * 4 + 3] + pose[p * 16 + r * 4 + 3]) / 2.0f) * a.coordinate_scale;
+            }
+            bl = a.bone_length[(size_t)b * (J - 1) + tid];
+        } else {   // center+head: the head joint's own frame, bone length 1
+            const int hj = 15;
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) R[r * 3 + c] = pose[hj * 16 + r * 4 + c];
+            for (int r = 0; r < 3; ++r) t[r] = exact_mul(pose[hj * 16 + r * 4 + 3], a.coordinate_scale);
+            bl = 1.0f;
+        }
+        for (int i = 0; i < 9; ++i) out[i] = R[i];
+        for (int i = 0; i < 3; ++i) out[9 + i] = t[i];
+        {
+#pragma clang fp contract(off)
+            out[12] = (a.canonical_bone_length[tid] / bl) / a.coordinate_scale;
+        }
+        out[13] = out[14] = out[15] = 0.0f;
+    }
+
+    // ---- modulated, demodulated weights (custom_stylegan2/net.py:233-243) in MFMA operand order
+    if (!a.mlp_pack) return;
+    float *pf = reinterpret_cast<float *>(reinterpret_cast<char *>(a.mlp_pack) + (size_t)b * kPackBytes);
+    short *ph = reinterpret_cast<short *>(pf + PK_F32_FLOATS);
+    for (int i = tid; i < PK_F32_FLOATS; i += 256) pf[i] = 0.0f;
+    for (int i = tid; i < PKH_SHORTS; i += 256) ph[i] = 0;
+    __syncthreads();
+    const float *z = a.z_rend + (size_t)b * a.style_dim;
+    const float mscale = 1.0f / sqrtf((float)a.style_dim);
+    for (int layer = 0; layer < 3; ++layer) {
+        const int cin = (layer == 0) ? kFeat : kHid;
+        const int cout = (layer == 2) ? 4 : kHid;
+        if (tid < cin) {   // EqualLinear: z @ (Wm * scale)^T + b_mod
+            const float *wm = a.mod_weight[layer] + (size_t)tid * a.style_dim;
+            float acc = 0.0f;
+            for (int d = 0; d < a.style_dim; ++d) acc += z[d] * (wm[d] * mscale);
+            s_style[tid] = acc + a.mod_bias[layer][tid];
+        }
+        __syncthreads();
+        const float cscale = 1.0f / sqrtf((float)cin);
+        for (int e = tid; e < cout * cin; e += 256) {
+            const int c = e % cin;
+            s_w[e] = (cscale * a.conv_weight[layer][e]) * s_style[c];
+        }
+        __syncthreads();
+        if (tid < cout) {   // F.normalize(dim=-1, eps=1e-12)
+            float ss = 0.0f;
+            for (int c = 0; c < cin; ++c) ss += s_w[tid * cin + c] * s_w[tid * cin + c];
+            const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+            for (int c = 0; c < cin; ++c) pack_weight_row(pf, ph, layer, tid, c, s_w[tid * cin + c] * inv);
+            const int boff = (layer == 0) ? PK_B1 : (layer == 1) ? PK_B2 : PK_B3;
+            pf[boff + tid] = a.bias[layer][tid];
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void mlp_unpack_kernel(const float *__restrict__ pf, float *__restrict__ dense) {
+    // dense: W1 (64,32) | W2 (64,64) | W3 (4,64) | b1 64 | b2 64 | b3 4
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid < 64 * 32) {
+        const int o = tid / 32, c = tid % 32;
+        dense[tid] = pf[PK_W1 + ((o >> 4) * 8 + (c & 7)) * 64 + (c >> 3) * 16 + (o & 15)];
+    } else if (tid < 64 * 32 + 64 * 64) {
+        const int e = tid - 64 * 32, o = e / 64, c = e % 64;
+        const int q = (c >> 4) * 4 + (c & 3), g = (c & 15) >> 2;
+        dense[tid] = pf[PK_W2 + ((o >> 4) * 16 + q) * 64 + g * 16 + (o & 15)];
+    } else if (tid < 64 * 32 + 64 * 64 + 4 * 64) {
+        const int e = tid - (64 * 32 + 64 * 64), o = e / 64, c = e % 64;
+        const int q = (c >> 4) * 4 + (c & 3), g = (c & 15) >> 2;
+        dense[tid] = pf[PK_W3 + q * 64 + g * 16 + o];
+    } else if (tid < 64 * 32 + 64 * 64 + 4 * 64 + 132) {
+        const int e = tid - (64 * 32 + 64 * 64 + 4 * 64);
+        dense[tid] = (e < 64) ? pf[PK_B1 + e] : (e < 128) ? pf[PK_B2 + e - 64] : pf[PK_B3 + e - 128];
+    }
+}
+
+// =================================================================================================
+// LDS staging shared by the query and render kernels
+// =================================================================================================
+// dynamic LDS layout (floats): [mlp section][bias 144][parts P*16][canon P*12][scratch 160]
+template <int MODE>
+__host__ __device__ constexpr int lds_mlp_floats() {
+    return (MODE == ENARF_MLP_F32) ? PK_B1 : PKH_SHORTS / 2;
+}
+template <int MODE>
+__host__ __device__ inline int lds_total_floats(int P) {
+    return lds_mlp_floats<MODE>() + 144 + P * kPartStride + P * 12 + 160;
+}
+
+template <int MODE>
+__device__ __forceinline__ void stage_common(float *lds, QueryCtx &S, float *&scratch, const void *pack_b,
+                                             const float *parts_b, const float *canon_pose, int P, int tid,
+                                             int nthreads) {
+    float *l_mlp = lds;
+    float *l_bias = l_mlp + lds_mlp_floats<MODE>();
+    float *l_parts = l_bias + 144;
+    float *l_canon = l_parts + P * kPartStride;
+    scratch = l_canon + P * 12;
+    const float *pf = reinterpret_cast<const float *>(pack_b);
+    const f32x4 *src4 = (MODE == ENARF_MLP_F32) ? reinterpret_cast<const f32x4 *>(pf)
+                                                : reinterpret_cast<const f32x4 *>(pf + PK_F32_FLOATS);
+    f32x4 *dst4 = reinterpret_cast<f32x4 *>(l_mlp);
+    for (int i = tid; i < lds_mlp_floats<MODE>() / 4; i += nthreads) dst4[i] = src4[i];
+    for (int i = tid; i < 144; i += nthreads) l_bias[i] = pf[PK_B1 + i];
+    for (int i = tid; i < P * kPartStride; i += nthreads) l_parts[i] = parts_b[i];
+    for (int i = tid; i < P * 12; i += nthreads) {   // (P,4,4) -> Rc row-major 9 + tc 3
+        const int k = i / 12, e = i % 12;
+        l_canon[i] = (e < 9) ? canon_pose[k * 16 + (e / 3) * 4 + (e % 3)] : canon_pose[k * 16 + (e - 9) * 4 + 3];
+    }
+    S.mlp = l_mlp;
+    S.mlp_h = reinterpret_cast<const short *>(l_mlp);
+    S.bias = l_bias;
+    S.parts = l_parts;
+    S.canon = l_canon;
+}
+
+// head: tanh colour, MyReLU * 10 density, density *= any_valid   (triplane_nerf.py:44-47, narf.py:271-274, :204)
+__device__ __forceinline__ float density_head(float sigma_act, uint32_t bits, float wmax, int mult_w, int P) {
+    float d = fmaxf(sigma_act, 0.0f);
+    if (mult_w) {
+        // max over ALL parts of the weight tensor; invalid parts sit at sigmoid(0)^3 = 0.125
+        const float wm = (__popc(bits) < P) ? fmaxf(wmax, 0.125f) : wmax;
+        d = d * (10.0f * wm);
+    } else {
+        d = d * 10.0f;
+    }
+    return bits ? d : 0.0f;
+}
+
+// =================================================================================================
+// enarf_query_fwd: a wave takes 64 consecutive points of one image
+// =================================================================================================
+template <int MODE, bool DBG>
+__global__ __launch_bounds__(256) void query_kernel(const enarf_query_args a, int wgs_per_image, int pts_per_wg) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = bid / wgs_per_image, chunk = bid % wgs_per_image;
+    QueryCtx S;
+    float *scratch;
+    stage_common<MODE>(lds, S, scratch, reinterpret_cast<const char *>(a.mlp_pack) + (size_t)b * kPackBytes,
+                       a.parts + (size_t)b * a.P * kPartStride, a.canonical_pose, a.P, tid, 256);
+    S.feat = a.feat_cl + (size_t)b * a.feat_batch_stride;
+    S.mask = a.mask_planes + (size_t)b * a.mask_batch_stride;
+    S.H = a.H; S.W = a.W; S.P = a.P; S.mult_w = a.multiply_density_with_weight;
+    __syncthreads();
+
+    // colour of a point with no valid part: the reference still runs the MLP on a zero feature
+    // (narf.py:255-268), a per-image constant; wave 0 computes it once per workgroup.
+    if (wave == 0) {
+        float zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const f32x4 o = mlp_tile<MODE>(S, zero, lane);
+        if (lane == 0) { scratch[0] = o[0]; scratch[1] = o[1]; scratch[2] = o[2]; }
+    }
+    __syncthreads();
+    const float c0r = tanhf(scratch[0]), c0g = tanhf(scratch[1]), c0b = tanhf(scratch[2]);
+
+    const long long N = a.N;
+    const uint32_t all_parts = (a.P >= 32) ? 0xFFFFFFFFu : ((1u << a.P) - 1u);
+    const long long base = (long long)chunk * pts_per_wg;
+    for (long long off = (long long)wave * 64; off < pts_per_wg; off += 256) {
+        const long long i = base + off + lane;
+        if (base + off >= N) break;   // uniform
+        const bool active = i < N;
+        const long long ic = active ? i : N - 1;
+        const float *pp = a.points + (size_t)b * 3 * N;
+        const float px = pp[ic], py = pp[N + ic], pz = pp[2 * N + ic];
+        QueryDbg dbg{nullptr, nullptr, N, ic};
+        if (DBG) {
+            dbg.canonical = a.dbg_canonical ? a.dbg_canonical + (size_t)b * a.P * 3 * N : nullptr;
+            dbg.weight = a.dbg_weight ? a.dbg_weight + (size_t)b * a.P * N : nullptr;
+        }
+        float h[4];
+        uint32_t bits;
+        float wmax;
+        uint64_t tiles;
+        unsigned np = 0, nt = 0;
+        query_wave<MODE, DBG>(S, all_parts, px, py, pz, active, lane, h, bits, wmax, tiles, dbg, np, nt);
+        if (active) {
+            const bool ran = (tiles >> lane) & 1ull;
+            a.density[(size_t)b * N + i] = density_head(h[3], bits, wmax, S.mult_w, S.P);
+            if (a.color) {
+                float *c = a.color + (size_t)b * 3 * N;
+                c[i] = ran ? tanhf(h[0]) : c0r;
+                c[N + i] = ran ? tanhf(h[1]) : c0g;
+                c[2 * N + i] = ran ? tanhf(h[2]) : c0b;
+            }
+            if (a.valid_bits) a.valid_bits[(size_t)b * N + i] = bits;
+        }
+    }
+}
+
+// =================================================================================================
+// enarf_render_fwd: one wavefront per ray; lanes = samples along the ray
+// =================================================================================================
+// bitonic sort of one value per lane, ascending across the wave
+__device__ __forceinline__ float wave_sort64(float v, int lane) {
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const float o = __shfl_xor(v, j);
+            const bool up = ((lane & k) == 0);
+            const bool lower = ((lane & j) == 0);
+            v = (lower == up) ? fminf(v, o) : fmaxf(v, o);
+        }
+    }
+    return v;
+}
+
+// conservative per-ray part culling: can the segment {dir * d : d in [d0, d1]} touch part k's cube?
+// (slab test in the part's local frame with a relative margin; the exact per-sample test still decides)
+__device__ __forceinline__ bool ray_hits_part(const float *F, float dx, float dy, float dz, float d0, float d1) {
+    const float ox = -(F[0] * F[9] + F[3] * F[10] + F[6] * F[11]);
+    const float oy = -(F[1] * F[9] + F[4] * F[10] + F[7] * F[11]);
+    const float oz = -(F[2] * F[9] + F[5] * F[10] + F[8] * F[11]);
+    const float lx = F[0] * dx + F[3] * dy + F[6] * dz;
+    const float ly = F[1] * dx + F[4] * dy + F[7] * dz;
+    const float lz = F[2] * dx + F[5] * dy + F[8] * dz;
+    const float lim = 1.0f + 1e-3f;
+    float t0 = d0, t1 = d1;
+    const float o[3] = {ox, oy, oz}, l[3] = {lx, ly, lz};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        if (fabsf(l[i]) < 1e-12f) {
+            if (fabsf(o[i]) > lim) return false;
+        } else {
+            const float inv = 1.0f / l[i];
+            float a = (-lim - o[i]) * inv, c = (lim - o[i]) * inv;
+            if (a > c) { const float tmp = a; a = c; c = tmp; }
+            t0 = fmaxf(t0, a - 1e-3f * fabsf(a));
+            t1 = fminf(t1, c + 1e-3f * fabsf(c));
+        }
+    }
+    return t0 <= t1;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void render_kernel(const enarf_render_args a, int wgs_per_image, int rays_per_wg) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = bid / wgs_per_image, tile = bid % wgs_per_image;
+    const int P = a.P, Nc = a.Nc, Nf = a.Nf, n = a.n;
+
+    QueryCtx S;
+    float *scratch;
+    stage_common<MODE>(lds, S, scratch, reinterpret_cast<const char *>(a.mlp_pack) + (size_t)b * kPackBytes,
+                       a.parts + (size_t)b * P * kPartStride, a.canonical_pose, P, tid, 256);
+    S.feat = a.feat_cl + (size_t)b * a.feat_batch_stride;
+    S.mask = a.mask_planes + (size_t)b * a.mask_batch_stride;
+    S.H = a.H; S.W = a.W; S.P = P; S.mult_w = a.multiply_density_with_weight;
+    float *l_dtab = scratch;          // 32 range-test depths
+    float *l_btab = scratch + 32;     // Nc + 1 bin edges (<= 65)
+    float *l_red = scratch + 100;     // 8 partials + near/far
+
+    // ---- batch-global near / far planes (rendering.py:15-17): min / max of every part centre's z
+    {
+        float mn = 3.0e38f, mx = -3.0e38f;
+        for (int i = tid; i < a.B * P; i += 256) {
+            const float z = a.parts[(size_t)i * kPartStride + 11];
+            mn = fminf(mn, z);
+            mx = fmaxf(mx, z);
+        }
+        mn = wave_min(mn);
+        mx = wave_max(mx);
+        if (lane == 0) { l_red[wave] = mn; l_red[4 + wave] = mx; }
+        __syncthreads();
+        if (tid == 0) {
+#pragma clang fp contract(off)
+            const float zmin = fminf(fminf(l_red[0], l_red[1]), fminf(l_red[2], l_red[3]));
+            const float zmax = fmaxf(fmaxf(l_red[4], l_red[5]), fmaxf(l_red[6], l_red[7]));
+            l_red[8] = fmaxf(zmin - 1.7320508075688772f, 0.3f);
+            l_red[9] = fmaxf(zmax + 1.7320508075688772f, 5.0f);
+        }
+        __syncthreads();
+    }
+    const float near_p = l_red[8], far_p = l_red[9];
+    if (tid < 32) l_dtab[tid] = linspace_sym(near_p, far_p, 32, tid);
+    if (tid <= Nc) l_btab[tid] = linspace_sym(0.0f, 1.0f, Nc + 1, tid);
+    __syncthreads();
+
+    unsigned n_pairs = 0, n_tiles = 0, n_rays = 0;
+    const float *coord = a.image_coord + (size_t)b * 3 * n;
+    const float *Ki = a.inv_intrinsics + (size_t)b * 9;
+    const QueryDbg nodbg{nullptr, nullptr, 0, 0};
+
+    for (int r = wave; r < rays_per_wg; r += 4) {
+        const int ray = __builtin_amdgcn_readfirstlane(tile * rays_per_wg + r);
+        if (ray >= n) break;
+        // ---- ray direction K^-1 [u v w]  (rendering.py:26-38)
+        const float u = coord[ray], v = coord[n + ray], w = coord[2 * n + ray];
+        const float dx = exact_dot3(Ki[0], u, Ki[1], v, Ki[2], w);
+        const float dy = exact_dot3(Ki[3], u, Ki[4], v, Ki[5], w);
+        const float dz = exact_dot3(Ki[6], u, Ki[7], v, Ki[8], w);
+
+        // ---- candidate parts over [near, far]: lane k tests part k
+        const uint32_t cand_all = (uint32_t)__ballot(lane < P &&
+                                                     ray_hits_part(S.parts + min(lane, P - 1) * kPartStride, dx, dy, dz, near_p, far_p));
+
+        // ---- depth range: 32 depths x parts cube test (rendering.py:40-70); lane = (depth, half of the parts)
+        float dmin, dmax;
+        bool ray_valid;
+        {
+            const int di = lane & 31, half = lane >> 5;
+            const float ds = l_dtab[di];
+            const float qx = exact_mul(dx, ds), qy = exact_mul(dy, ds), qz = exact_mul(dz, ds);
+            bool inside = false;
+            uint32_t m = cand_all;
+            while (m) {   // the two 32-lane halves take alternate candidate parts
+                const int k0 = __builtin_ctz(m);
+                m &= m - 1;
+                int k1 = -1;
+                if (m) { k1 = __builtin_ctz(m); m &= m - 1; }
+                const int k = half ? k1 : k0;
+                if (k >= 0) {
+                    float lx, ly, lz;
+                    exact_local(S.parts + k * kPartStride, qx, qy, qz, lx, ly, lz);
+                    inside = inside || in_unit_cube_incl(lx, ly, lz);
+                }
+            }
+            dmin = wave_min(inside ? ds : 1.0e3f);
+            dmax = wave_max(inside ? ds : -1.0e3f);
+            ray_valid = (dmin != 1.0e3f);
+            dmin = ray_valid ? dmin : near_p;
+            dmax = (dmax != -1.0e3f) ? dmax : far_p;
+            dmin = fmaxf(dmin, near_p);
+        }
+        if (a.dbg_depth_min && lane == 0) {
+            a.dbg_depth_min[(size_t)b * n + ray] = dmin;
+            a.dbg_depth_max[(size_t)b * n + ray] = dmax;
+            a.dbg_ray_valid[(size_t)b * n + ray] = ray_valid ? 1 : 0;
+        }
+        if (a.drop_invalid_rays && !ray_valid) {   // rendering.py:107-110 / :337-350: zeros
+            if (lane < 3) a.color[((size_t)b * 3 + lane) * n + ray] = 0.0f;
+            if (lane == 3) a.mask[(size_t)b * n + ray] = 0.0f;
+            if (lane == 4) a.disparity[(size_t)b * n + ray] = 0.0f;
+            if (a.fine_weights && lane < Nf - 1) a.fine_weights[((size_t)b * n + ray) * (Nf - 1) + lane] = 0.0f;
+            if (a.fine_depth && lane < Nf) a.fine_depth[((size_t)b * n + ray) * Nf + lane] = 0.0f;
+            continue;
+        }
+        n_rays += 1;
+        // candidate parts over the marched segment only
+        const uint32_t cand = (uint32_t)__ballot(lane < P && ((cand_all >> lane) & 1u) &&
+                                                 ray_hits_part(S.parts + min(lane, P - 1) * kPartStride, dx, dy, dz, dmin, dmax));
+        const float sx = exact_mul(dmin, dx), sy = exact_mul(dmin, dy), sz = exact_mul(dmin, dz);
+        const float ex = exact_mul(dmax, dx), ey = exact_mul(dmax, dy), ez = exact_mul(dmax, dz);
+
+        // ---- coarse pass: lane i < Nc is the mid-point of bin i (rendering.py:119-131)
+        float ws;   // smoothed coarse weight of this lane's bin
+        {
+            const int ci = min(lane, Nc - 1);
+            const float b0 = l_btab[ci], b1 = l_btab[ci + 1];
+            const float px = exact_mid(exact_lerp(sx, ex, b1), exact_lerp(sx, ex, b0));
+            const float py = exact_mid(exact_lerp(sy, ey, b1), exact_lerp(sy, ey, b0));
+            const float pz = exact_mid(exact_lerp(sz, ez, b1), exact_lerp(sz, ez, b0));
+            const float delta = exact_lerp(dmin, dmax, b1) - exact_lerp(dmin, dmax, b0);
+            const bool active = lane < Nc;
+            float h[4], wmax;
+            uint32_t bits;
+            uint64_t tiles;
+            query_wave<MODE, false>(S, cand, px, py, pz, active, lane, h, bits, wmax, tiles, nodbg, n_pairs, n_tiles);
+            const float den = active ? density_head(h[3], bits, wmax, S.mult_w, P) : 0.0f;
+            if (a.dbg_coarse_density && active) a.dbg_coarse_density[((size_t)b * n + ray) * Nc + lane] = den;
+            // weights (rendering.py:180-184) and smoothing (:187-190)
+            const float dd = active ? den * delta * a.render_scale : 0.0f;
+            const float cs = wave_scan_incl(dd, lane);
+            const float T = expf(-(cs - dd));
+            const float wgt = active ? T * (1.0f - expf(-dd)) : 0.0f;
+            float wl = __shfl_up(wgt, 1), wr = __shfl_down(wgt, 1);
+            if (lane == 0) wl = 0.0f;
+            if (lane >= Nc - 1) wr = 0.0f;
+            ws = active ? (fmaxf(wl, wgt) + fmaxf(wgt, wr)) / 2.0f + 0.01f : 0.0f;
+        }
+
+        // ---- importance samples (rendering.py:192-200)
+        float bin;
+        if (a.bins) {
+            bin = a.bins[((size_t)b * n + ray) * Nf + min(lane, Nf - 1)];
+        } else {
+            const float cdf = wave_scan_incl(ws, lane);
+            const float total = __shfl(cdf, Nc - 1);
+            uint32_t rnd[4];
+            const uint64_t gid = (uint64_t)b * (uint64_t)n + (uint64_t)ray;
+            philox4x32((uint32_t)gid, (uint32_t)(gid >> 32), (uint32_t)lane, 0x454E4152u,
+                       (uint32_t)a.seed, (uint32_t)(a.seed >> 32), rnd);
+            const float target = u32_to_unit(rnd[0]) * total;
+            int lo = 0, hi = Nc - 1;   // smallest i with cdf[i] > target
+#pragma unroll
+            for (int it = 0; it < 6; ++it) {
+                const int mid = (lo + hi) >> 1;
+                const float c = __shfl(cdf, mid);
+                if (lo < hi) { if (c > target) hi = mid; else lo = mid + 1; }
+            }
+            const float raw = (float)lo / (float)Nc + u32_to_unit(rnd[1]) / (float)Nc;
+            bin = wave_sort64(lane < Nf ? raw : 3.0e38f, lane);
+        }
+        if (a.dbg_bins && lane < Nf) a.dbg_bins[((size_t)b * n + ray) * Nf + lane] = bin;
+
+        // ---- fine pass + compositing (rendering.py:283-335); the last sample only closes the last interval
+        {
+            const float fdepth = exact_lerp(dmin, dmax, bin);
+            const float px = exact_lerp(sx, ex, bin), py = exact_lerp(sy, ey, bin), pz = exact_lerp(sz, ez, bin);
+            const bool dbgq = (a.dbg_fine_density != nullptr);
+            const bool active = dbgq ? (lane < Nf) : (lane < Nf - 1);
+            float h[4], wmax;
+            uint32_t bits;
+            uint64_t tiles;
+            query_wave<MODE, false>(S, cand, px, py, pz, active, lane, h, bits, wmax, tiles, nodbg, n_pairs, n_tiles);
+            const float den = active ? density_head(h[3], bits, wmax, S.mult_w, P) : 0.0f;
+            const float cr = tanhf(h[0]), cg = tanhf(h[1]), cb = tanhf(h[2]);
+            if (dbgq && lane < Nf) {
+                const size_t o = ((size_t)b * n + ray) * Nf + lane;
+                a.dbg_fine_density[o] = den;
+                if (a.dbg_fine_valid) a.dbg_fine_valid[o] = bits;
+                if (a.dbg_fine_color) {
+                    a.dbg_fine_color[(((size_t)b * 3 + 0) * n + ray) * Nf + lane] = cr;
+                    a.dbg_fine_color[(((size_t)b * 3 + 1) * n + ray) * Nf + lane] = cg;
+                    a.dbg_fine_color[(((size_t)b * 3 + 2) * n + ray) * Nf + lane] = cb;
+                }
+            }
+            const bool seg = lane < Nf - 1;
+            const float dnext = __shfl_down(fdepth, 1);
+            const float dd = seg ? den * (dnext - fdepth) * a.render_scale : 0.0f;
+            const float cs = wave_scan_incl(dd, lane);
+            const float T = expf(-(cs - dd));
+            const float wgt = seg ? T * (1.0f - expf(-dd)) : 0.0f;
+            const float o_r = wave_sum(wgt * cr), o_g = wave_sum(wgt * cg), o_b = wave_sum(wgt * cb);
+            const float o_m = wave_sum(wgt);
+            const float o_d = wave_sum(seg ? (wgt * 1.0f) / fdepth : 0.0f);
+            if (lane == 0) {
+                a.color[((size_t)b * 3 + 0) * n + ray] = o_r;
+                a.color[((size_t)b * 3 + 1) * n + ray] = o_g;
+                a.color[((size_t)b * 3 + 2) * n + ray] = o_b;
+                a.mask[(size_t)b * n + ray] = o_m;
+                a.disparity[(size_t)b * n + ray] = o_d;
+            }
+            if (a.fine_weights && seg) a.fine_weights[((size_t)b * n + ray) * (Nf - 1) + lane] = wgt;
+            if (a.fine_depth && lane < Nf) a.fine_depth[((size_t)b * n + ray) * Nf + lane] = fdepth;
+        }
+    }
+    if (a.counters && lane == 0) {
+        atomicAdd(&a.counters[0], (unsigned long long)n_pairs);
+        atomicAdd(&a.counters[1], (unsigned long long)n_tiles);
+        atomicAdd(&a.counters[2], (unsigned long long)n_rays);
+    }
+}
+
+}  // namespace enarf
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+using namespace enarf;
+
+extern "C" int enarf_abi_version(void) { return ENARF_ABI_VERSION; }
+extern "C" const char *enarf_last_error(void) { return host::last_error(); }
+extern "C" size_t enarf_mlp_pack_bytes(void) { return kPackBytes; }
+
+extern "C" int enarf_prepare(const enarf_prepare_args *args, enarf_stream_t stream) {
+    if (!args) return host::fail(ENARF_ERR_ARG, "enarf_prepare: args is null");
+    const enarf_prepare_args &a = *args;
+    if (a.B <= 0 || a.num_joints < 2 || a.num_joints > ENARF_MAX_JOINTS || a.style_dim <= 0)
+        return host::fail(ENARF_ERR_ARG, "enarf_prepare: bad sizes (B=%d joints=%d style_dim=%d)", a.B, a.num_joints, a.style_dim);
+    if (a.origin_location < 0 || a.origin_location > 2) return host::fail(ENARF_ERR_ARG, "enarf_prepare: bad origin_location %d", a.origin_location);
+    if (a.origin_location == ENARF_ORIGIN_CENTER_HEAD && a.num_joints <= 15)
+        return host::fail(ENARF_ERR_ARG, "enarf_prepare: center+head needs joint 15 (head)");
+    if (a.parts && (!a.pose_to_camera || !a.bone_length || !a.canonical_bone_length))
+        return host::fail(ENARF_ERR_ARG, "enarf_prepare: pose / bone_length / canonical_bone_length pointer is null");
+    if (a.mlp_pack) {
+        if (!a.z_rend) return host::fail(ENARF_ERR_ARG, "enarf_prepare: z_rend is null");
+        for (int i = 0; i < 3; ++i)
+            if (!a.conv_weight[i] || !a.mod_weight[i] || !a.mod_bias[i] || !a.bias[i])
+                return host::fail(ENARF_ERR_ARG, "enarf_prepare: MLP parameter pointer of layer %d is null", i);
+    }
+    for (int j = 1; j < a.num_joints; ++j)
+        if (a.parents[j] < 0 || a.parents[j] >= a.num_joints) return host::fail(ENARF_ERR_ARG, "enarf_prepare: parents[%d]=%d out of range", j, a.parents[j]);
+    PrepareParams prm;
+    prm.a = a;
+    hipLaunchKernelGGL(prepare_kernel, dim3(a.B), dim3(256), 0, (hipStream_t)stream, prm);
+    return host::check_launch("enarf_prepare");
+}
+
+extern "C" int enarf_mlp_unpack(const void *pack, float *dense, enarf_stream_t stream) {
+    if (!pack || !dense) return host::fail(ENARF_ERR_ARG, "enarf_mlp_unpack: null pointer");
+    hipLaunchKernelGGL(mlp_unpack_kernel, dim3(27), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float *>(pack), dense);
+    return host::check_launch("enarf_mlp_unpack");
+}
+
+template <int MODE>
+static int launch_query(const enarf_query_args &a, hipStream_t st) {
+    const int pts_per_wg = 1024;
+    const long long wgs = (a.N + pts_per_wg - 1) / pts_per_wg;
+    if (wgs * a.B > 0x7FFFFFFFll) return host::fail(ENARF_ERR_UNSUPPORTED, "enarf_query_fwd: too many points for one launch");
+    const size_t lds = (size_t)lds_total_floats<MODE>(a.P) * 4;
+    const bool dbg = a.dbg_canonical || a.dbg_weight;
+    auto k = dbg ? query_kernel<MODE, true> : query_kernel<MODE, false>;
+    hipLaunchKernelGGL(k, dim3((unsigned)(wgs * a.B)), dim3(256), lds, st, a, (int)wgs, pts_per_wg);
+    return host::check_launch("enarf_query_fwd");
+}
+
+static int check_common(const char *who, int B, int P, int H, int W, int mode, const void *parts, const void *canon,
+                        const void *feat, const void *mask, const void *pack) {
+    if (B <= 0 || P <= 0 || P > ENARF_MAX_PARTS) return host::fail(ENARF_ERR_ARG, "%s: bad B=%d or P=%d (max %d parts)", who, B, P, ENARF_MAX_PARTS);
+    if (H <= 0 || W <= 0) return host::fail(ENARF_ERR_ARG, "%s: bad plane size %dx%d", who, H, W);
+    if (mode < 0 || mode > 2) return host::fail(ENARF_ERR_ARG, "%s: bad mlp_mode %d", who, mode);
+    if (!parts || !canon || !feat || !mask || !pack) return host::fail(ENARF_ERR_ARG, "%s: null input pointer", who);
+    return 0;
+}
+
+extern "C" int enarf_query_fwd(const enarf_query_args *args, enarf_stream_t stream) {
+    if (!args) return host::fail(ENARF_ERR_ARG, "enarf_query_fwd: args is null");
+    const enarf_query_args &a = *args;
+    if (int rc = check_common("enarf_query_fwd", a.B, a.P, a.H, a.W, a.mlp_mode, a.parts, a.canonical_pose, a.feat_cl,
+                              a.mask_planes, a.mlp_pack)) return rc;
+    if (a.N < 0 || !a.points || !a.density) return host::fail(ENARF_ERR_ARG, "enarf_query_fwd: bad N or null points/density");
+    if (a.N == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    switch (a.mlp_mode) {
+        case ENARF_MLP_F32: return launch_query<ENARF_MLP_F32>(a, st);
+        case ENARF_MLP_BF16X3: return launch_query<ENARF_MLP_BF16X3>(a, st);
+        default: return launch_query<ENARF_MLP_BF16>(a, st);
+    }
+}
+
+template <int MODE>
+static int launch_render(const enarf_render_args &a, hipStream_t st) {
+    // rays per workgroup: enough workgroups to fill 256 CUs several times over, few enough that the
+    // per-workgroup LDS staging (~30 KB) is amortised
+    const long long total = (long long)a.B * a.n;
+    int rpw = 64;
+    while (rpw > 8 && total / rpw < 4096) rpw >>= 1;
+    const int wgs = (a.n + rpw - 1) / rpw;
+    const size_t lds = (size_t)lds_total_floats<MODE>(a.P) * 4;
+    hipLaunchKernelGGL(render_kernel<MODE>, dim3((unsigned)(wgs * a.B)), dim3(256), lds, st, a, wgs, rpw);
+    return host::check_launch("enarf_render_fwd");
+}
+
+extern "C" int enarf_render_fwd(const enarf_render_args *args, enarf_stream_t stream) {
+    if (!args) return host::fail(ENARF_ERR_ARG, "enarf_render_fwd: args is null");
+    const enarf_render_args &a = *args;
+    if (int rc = check_common("enarf_render_fwd", a.B, a.P, a.H, a.W, a.mlp_mode, a.parts, a.canonical_pose, a.feat_cl,
+                              a.mask_planes, a.mlp_pack)) return rc;
+    if (a.n <= 0 || !a.image_coord || !a.inv_intrinsics || !a.color || !a.mask || !a.disparity)
+        return host::fail(ENARF_ERR_ARG, "enarf_render_fwd: bad n or null ray/output pointer");
+    if (a.Nc < 2 || a.Nf < 2) return host::fail(ENARF_ERR_ARG, "enarf_render_fwd: Nc and Nf must be >= 2 (got %d, %d)", a.Nc, a.Nf);
+    if (a.Nc > 64 || a.Nf > 64)
+        return host::fail(ENARF_ERR_UNSUPPORTED, "enarf_render_fwd: Nc=%d / Nf=%d: more than 64 samples per pass is not implemented "
+                                                 "(one lane per sample)", a.Nc, a.Nf);
+    if (a.dbg_depth_min && (!a.dbg_depth_max || !a.dbg_ray_valid))
+        return host::fail(ENARF_ERR_ARG, "enarf_render_fwd: dbg_depth_min needs dbg_depth_max and dbg_ray_valid");
+    if ((long long)((a.n + 7) / 8) * a.B > 0x7FFFFFFFll) return host::fail(ENARF_ERR_UNSUPPORTED, "enarf_render_fwd: too many rays for one launch");
+    hipStream_t st = (hipStream_t)stream;
+    switch (a.mlp_mode) {
+        case ENARF_MLP_F32: return launch_render<ENARF_MLP_F32>(a, st);
+        case ENARF_MLP_BF16X3: return launch_render<ENARF_MLP_BF16X3>(a, st);
+        default: return launch_render<ENARF_MLP_BF16>(a, st);
+    }
+}

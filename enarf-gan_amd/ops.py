@@ -1,0 +1,266 @@
+"""Tensor-level wrappers of the C ABI: torch supplies device memory and the current HIP stream,
+nothing else. Every function here requires CUDA(=HIP) tensors and raises otherwise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import FEAT_DIM, MLP_MODE, ORIGIN
+
+PLANE_CH = 3 * FEAT_DIM   # 96 feature channels precede the part-probability planes (models/narf.py:239,255)
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _stream(dev: torch.device) -> int:
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def _dev_f32(t: torch.Tensor, what: str) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _lib.EnarfHipError(f"{what} must be a CUDA/HIP tensor (enarf_gan_amd has no CPU path)")
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def mlp_pack_bytes() -> int:
+    return int(_lib.load().enarf_mlp_pack_bytes())
+
+
+def num_parts(num_joints: int, origin_location: str) -> int:
+    return num_joints if origin_location == "center+head" else num_joints - 1
+
+
+# ---------------------------------------------------------------------------------------- a1 operator
+def triplane_sample_fwd(inp: torch.Tensor, grid: torch.Tensor, mode: int = 0, padding_mode: int = 0,
+                        align_corners: bool = False, use_workspace: bool = True) -> torch.Tensor:
+    """input (B,3C,H,W), grid (B,h,w,3) -> (B,C,h,w); cuda_extension/TriplaneSampler.cpp:15-24."""
+    lib = _lib.load()
+    inp = _dev_f32(inp, "input")
+    grid = _dev_f32(grid, "grid")
+    B, C3, H, W = inp.shape
+    if C3 % 3 != 0 or grid.shape[0] != B or grid.shape[-1] != 3 or grid.dim() != 4:
+        raise ValueError(f"triplane_sampler: input {tuple(inp.shape)} / grid {tuple(grid.shape)} shapes do not match "
+                         "(B,3C,H,W) / (B,h,w,3)")
+    h, w = grid.shape[1], grid.shape[2]
+    Cc = C3 // 3
+    out = torch.empty(B, Cc, h, w, dtype=torch.float32, device=inp.device)
+    ws = None
+    if use_workspace:
+        nbytes = lib.enarf_triplane_sample_workspace_bytes(B, Cc, H, W)
+        if nbytes:
+            ws = torch.empty(nbytes // 4, dtype=torch.float32, device=inp.device)
+    rc = lib.enarf_triplane_sample_fwd(_p(inp), _p(grid), _p(out), B, Cc, H, W, h * w, mode, padding_mode,
+                                       int(bool(align_corners)), _p(ws), _stream(inp.device))
+    _lib.check(rc, "enarf_triplane_sample_fwd")
+    return out
+
+
+def triplane_sample_bwd(grad_out: torch.Tensor, inp: torch.Tensor, grid: torch.Tensor, mode: int, padding_mode: int,
+                        align_corners: bool, need_input: bool, need_grid: bool
+                        ) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
+    """cuda_extension/TriplaneSampler.cpp:26-52; returns (grad_input, grad_grid), None where not needed."""
+    lib = _lib.load()
+    grad_out = _dev_f32(grad_out, "grad_output")
+    inp = _dev_f32(inp, "input")
+    grid = _dev_f32(grid, "grid")
+    B, C3, H, W = inp.shape
+    h, w = grid.shape[1], grid.shape[2]
+    gi = torch.zeros_like(inp) if need_input else None
+    gg = torch.empty_like(grid) if need_grid else None
+    rc = lib.enarf_triplane_sample_bwd(_p(grad_out), _p(inp), _p(grid), _p(gi), _p(gg), B, C3 // 3, H, W, h * w,
+                                       mode, padding_mode, int(bool(align_corners)), None, _stream(inp.device))
+    _lib.check(rc, "enarf_triplane_sample_bwd")
+    return gi, gg
+
+
+# ---------------------------------------------------------------------------------------- re-layout
+def triplane_pack(tri_nchw: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """(B, 96+3P, H, W) NCHW -> feature planes channel-last (B, 3, H, W, 32)."""
+    lib = _lib.load()
+    tri = _dev_f32(tri_nchw, "tri_plane")
+    B, Ct, H, W = tri.shape
+    if out is None:
+        out = torch.empty(B, 3, H, W, FEAT_DIM, dtype=torch.float32, device=tri.device)
+    rc = lib.enarf_triplane_pack(_p(tri), _p(out), B, Ct, H, W, _stream(tri.device))
+    _lib.check(rc, "enarf_triplane_pack")
+    return out
+
+
+# ---------------------------------------------------------------------------------------- prepare
+def prepare(pose_to_camera: torch.Tensor, bone_length: torch.Tensor, canonical_bone_length: torch.Tensor,
+            z_rend: torch.Tensor, mlp: Dict[str, torch.Tensor], parents: Sequence[int], origin_location: str,
+            coordinate_scale: float, parts_out: Optional[torch.Tensor] = None,
+            pack_out: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """24 joints -> part frames (B,P,16) and the per-image MLP pack (B, pack_bytes) uint8."""
+    lib = _lib.load()
+    pose = _dev_f32(pose_to_camera, "pose_to_camera")
+    B, J = pose.shape[0], pose.shape[1]
+    P = num_parts(J, origin_location)
+    bl = _dev_f32(bone_length, "bone_length").reshape(B, J - 1)
+    cbl = _dev_f32(canonical_bone_length, "canonical_bone_length")
+    z = _dev_f32(z_rend, "z_rend")
+    if cbl.numel() != P:
+        raise ValueError(f"canonical_bone_length has {cbl.numel()} entries, expected {P}")
+    a = _lib.PrepareArgs()
+    a.B, a.num_joints, a.origin_location, a.style_dim = B, J, ORIGIN[origin_location], z.shape[1]
+    a.coordinate_scale = float(coordinate_scale)
+    par = np.asarray(parents, dtype=np.int64)
+    for j in range(J):
+        a.parents[j] = int(par[j])
+    a.pose_to_camera, a.bone_length, a.canonical_bone_length, a.z_rend = _p(pose), _p(bl), _p(cbl), _p(z)
+    keep = []
+    dims = [(FEAT_DIM, 64), (64, 64), (64, 4)]
+    for i, (cin, cout) in enumerate(dims):
+        cw = _dev_f32(mlp[f"layers.{i}.conv.weight"], "conv.weight")
+        mw = _dev_f32(mlp[f"layers.{i}.conv.modulation.weight"], "modulation.weight")
+        mb = _dev_f32(mlp[f"layers.{i}.conv.modulation.bias"], "modulation.bias")
+        bs = _dev_f32(mlp[f"layers.{i}.bias"], "bias")
+        if cw.numel() != cin * cout or mw.shape != (cin, z.shape[1]) or mb.numel() != cin or bs.numel() != cout:
+            raise ValueError(f"StyledMLP layer {i}: unexpected parameter shapes "
+                             f"{tuple(cw.shape)} {tuple(mw.shape)} {tuple(mb.shape)} {tuple(bs.shape)}")
+        keep += [cw, mw, mb, bs]
+        a.conv_weight[i], a.mod_weight[i], a.mod_bias[i], a.bias[i] = _p(cw), _p(mw), _p(mb), _p(bs)
+    if parts_out is None:
+        parts_out = torch.empty(B, P, 16, dtype=torch.float32, device=pose.device)
+    if pack_out is None:
+        pack_out = torch.empty(B, mlp_pack_bytes(), dtype=torch.uint8, device=pose.device)
+    a.parts, a.mlp_pack = _p(parts_out), _p(pack_out)
+    rc = lib.enarf_prepare(C.byref(a), _stream(pose.device))
+    _lib.check(rc, "enarf_prepare")
+    return parts_out, pack_out
+
+
+def mlp_unpack(pack_one_image: torch.Tensor):
+    """Dense (W1 (64,32), W2 (64,64), W3 (4,64), b1, b2, b3) from one image's pack (tests / interop)."""
+    lib = _lib.load()
+    dense = torch.empty(64 * 32 + 64 * 64 + 4 * 64 + 132, dtype=torch.float32, device=pack_one_image.device)
+    _lib.check(lib.enarf_mlp_unpack(_p(pack_one_image), _p(dense), _stream(dense.device)), "enarf_mlp_unpack")
+    o = 0
+    outs = []
+    for shp in ((64, 32), (64, 64), (4, 64), (64,), (64,), (4,)):
+        n = int(np.prod(shp))
+        outs.append(dense[o:o + n].reshape(shp))
+        o += n
+    return outs
+
+
+def _plane_strides(tri_nchw: torch.Tensor, feat_cl: torch.Tensor, B: int):
+    """Batch strides (in floats) of the mask planes inside tri_nchw and of feat_cl; 0 = shared tri-plane."""
+    Ct, H, W = tri_nchw.shape[1:]
+    mask_stride = 0 if tri_nchw.shape[0] == 1 else Ct * H * W
+    feat_stride = 0 if feat_cl.shape[0] == 1 else 3 * H * W * FEAT_DIM
+    if tri_nchw.shape[0] not in (1, B) or feat_cl.shape[0] not in (1, B):
+        raise ValueError("tri-plane batch must be 1 (shared) or B")
+    return mask_stride, feat_stride
+
+
+# ---------------------------------------------------------------------------------------- a9 query
+def query_fwd(points: torch.Tensor, parts: torch.Tensor, canonical_pose: torch.Tensor, tri_nchw: torch.Tensor,
+              feat_cl: torch.Tensor, mlp_pack: torch.Tensor, mlp_mode: str = "f32",
+              multiply_density_with_weight: bool = False, need_color: bool = True, need_valid: bool = False,
+              debug: bool = False):
+    """points (B,3,N) -> density (B,1,N), color (B,3,N) [, valid_bits (B,N) int32 [, canonical, weight]]."""
+    lib = _lib.load()
+    pts = _dev_f32(points, "points")
+    B, _, N = pts.shape
+    P = parts.shape[1]
+    tri = _dev_f32(tri_nchw, "tri_plane")
+    H, W = tri.shape[2], tri.shape[3]
+    mstride, fstride = _plane_strides(tri, feat_cl, B)
+    dev = pts.device
+    den = torch.empty(B, 1, N, dtype=torch.float32, device=dev)
+    col = torch.empty(B, 3, N, dtype=torch.float32, device=dev) if need_color else None
+    vb = torch.empty(B, N, dtype=torch.int32, device=dev) if (need_valid or debug) else None
+    dc = torch.zeros(B, P, 3, N, dtype=torch.float32, device=dev) if debug else None
+    dw = torch.zeros(B, P, N, dtype=torch.float32, device=dev) if debug else None
+    a = _lib.QueryArgs()
+    a.B, a.N, a.P, a.H, a.W = B, N, P, H, W
+    a.mlp_mode, a.multiply_density_with_weight = MLP_MODE[mlp_mode], int(multiply_density_with_weight)
+    a.points, a.parts, a.canonical_pose = _p(pts), _p(parts), _p(_dev_f32(canonical_pose, "canonical_pose"))
+    a.feat_cl, a.feat_batch_stride = _p(feat_cl), fstride
+    a.mask_planes, a.mask_batch_stride = tri.data_ptr() + PLANE_CH * H * W * 4, mstride
+    a.mlp_pack, a.density, a.color, a.valid_bits = _p(mlp_pack), _p(den), _p(col), _p(vb)
+    a.dbg_canonical, a.dbg_weight = _p(dc), _p(dw)
+    _lib.check(lib.enarf_query_fwd(C.byref(a), _stream(dev)), "enarf_query_fwd")
+    out = (den, col)
+    if need_valid or debug:
+        out = out + (vb,)
+    if debug:
+        out = out + (dc, dw)
+    return out
+
+
+# ---------------------------------------------------------------------------------------- a13 render
+class RenderOutputs:
+    __slots__ = ("color", "mask", "disparity", "fine_weights", "fine_depth", "taps", "counters")
+
+
+def render_fwd(image_coord: torch.Tensor, inv_intrinsics: torch.Tensor, parts: torch.Tensor,
+               canonical_pose: torch.Tensor, tri_nchw: torch.Tensor, feat_cl: torch.Tensor, mlp_pack: torch.Tensor,
+               Nc: int, Nf: int, render_scale: float = 1.0, bins: Optional[torch.Tensor] = None, seed: int = 0,
+               mlp_mode: str = "f32", multiply_density_with_weight: bool = False,
+               drop_invalid_rays: Optional[bool] = None, want_fine: bool = True, debug: bool = False,
+               count: bool = False, early_stop_eps: float = 0.0) -> RenderOutputs:
+    """The fused ray march. image_coord (B,1,3,n) or (B,3,n); returns color (B,3,n), mask (B,n), disparity (B,n),
+    fine_weights (B,1,n,Nf-1), fine_depth (B,1,n,Nf) and, with debug=True, the parity taps."""
+    lib = _lib.load()
+    coord = _dev_f32(image_coord, "image_coord")
+    B, n = coord.shape[0], coord.shape[-1]
+    coord = coord.reshape(B, 3, n)
+    Ki = _dev_f32(inv_intrinsics, "inv_intrinsics")
+    if Ki.dim() == 2:
+        Ki = Ki[None].expand(B, -1, -1).contiguous()
+    P = parts.shape[1]
+    tri = _dev_f32(tri_nchw, "tri_plane")
+    H, W = tri.shape[2], tri.shape[3]
+    mstride, fstride = _plane_strides(tri, feat_cl, B)
+    dev = coord.device
+    o = RenderOutputs()
+    o.color = torch.empty(B, 3, n, dtype=torch.float32, device=dev)
+    o.mask = torch.empty(B, n, dtype=torch.float32, device=dev)
+    o.disparity = torch.empty(B, n, dtype=torch.float32, device=dev)
+    o.fine_weights = torch.empty(B, 1, n, Nf - 1, dtype=torch.float32, device=dev) if want_fine else None
+    o.fine_depth = torch.empty(B, 1, n, Nf, dtype=torch.float32, device=dev) if want_fine else None
+    o.taps, o.counters = None, None
+    a = _lib.RenderArgs()
+    a.B, a.n, a.P, a.Nc, a.Nf, a.H, a.W = B, n, P, Nc, Nf, H, W
+    a.mlp_mode, a.multiply_density_with_weight = MLP_MODE[mlp_mode], int(multiply_density_with_weight)
+    a.drop_invalid_rays = int(B == 1 if drop_invalid_rays is None else drop_invalid_rays)
+    a.render_scale, a.early_stop_eps = float(render_scale), float(early_stop_eps)
+    a.image_coord, a.inv_intrinsics, a.parts = _p(coord), _p(Ki), _p(parts)
+    a.canonical_pose = _p(_dev_f32(canonical_pose, "canonical_pose"))
+    a.feat_cl, a.feat_batch_stride = _p(feat_cl), fstride
+    a.mask_planes, a.mask_batch_stride = tri.data_ptr() + PLANE_CH * H * W * 4, mstride
+    a.mlp_pack = _p(mlp_pack)
+    if bins is not None:
+        bins = _dev_f32(bins, "bins").reshape(B, n, Nf)
+    a.bins, a.seed = _p(bins), int(seed) & 0xFFFFFFFFFFFFFFFF
+    a.color, a.mask, a.disparity = _p(o.color), _p(o.mask), _p(o.disparity)
+    a.fine_weights, a.fine_depth = _p(o.fine_weights), _p(o.fine_depth)
+    if debug:
+        t = {
+            "depth_min": torch.zeros(B, n, device=dev), "depth_max": torch.zeros(B, n, device=dev),
+            "ray_validity": torch.zeros(B, n, dtype=torch.uint8, device=dev),
+            "coarse_density": torch.zeros(B, n, Nc, device=dev), "fine_density": torch.zeros(B, n, Nf, device=dev),
+            "fine_color": torch.zeros(B, 3, n, Nf, device=dev),
+            "fine_valid": torch.zeros(B, n, Nf, dtype=torch.int32, device=dev),
+            "bins": torch.zeros(B, n, Nf, device=dev),
+        }
+        a.dbg_depth_min, a.dbg_depth_max, a.dbg_ray_valid = _p(t["depth_min"]), _p(t["depth_max"]), _p(t["ray_validity"])
+        a.dbg_coarse_density, a.dbg_fine_density = _p(t["coarse_density"]), _p(t["fine_density"])
+        a.dbg_fine_color, a.dbg_fine_valid, a.dbg_bins = _p(t["fine_color"]), _p(t["fine_valid"]), _p(t["bins"])
+        o.taps = t
+    if count:
+        o.counters = torch.zeros(4, dtype=torch.int64, device=dev)
+        a.counters = _p(o.counters)
+    _lib.check(lib.enarf_render_fwd(C.byref(a), _stream(dev)), "enarf_render_fwd")
+    return o

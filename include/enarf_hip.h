@@ -1,0 +1,201 @@
+/*
+ * enarf_hip.h - C ABI of libenarf_hip.so: the MI355X (gfx950) implementation of ENARF-GAN's per-ray
+ * rendering hot path. Plain pointers and sizes only; every pointer named "device" is a HIP device
+ * pointer to contiguous fp32 (unless stated), every call is asynchronous on `stream` (a hipStream_t
+ * passed as void*, NULL = the null stream) and returns 0 on success, a negative ENARF_ERR_* for an
+ * argument it rejects, or a positive hipError_t. enarf_last_error() gives the message (thread local).
+ *
+ * Each entry point names the reference interface (nogu-atsu/ENARF-GAN, file:line) it replaces; the
+ * reference-side binding a maintainer would add is shown in INTEGRATION.md.
+ */
+#ifndef ENARF_HIP_H
+#define ENARF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ENARF_ABI_VERSION 1
+
+#define ENARF_ERR_ARG          (-1)   /* null pointer / non-positive size / bad enum */
+#define ENARF_ERR_UNSUPPORTED  (-2)   /* valid in the reference but not implemented here (message says what) */
+
+#define ENARF_FEAT_DIM   32           /* models/narf.py:22 */
+#define ENARF_HIDDEN     64           /* models/narf.py:77 StyledMLP(32, 64, 4) */
+#define ENARF_MAX_PARTS  32           /* validity bit masks are uint32; the reference uses 23 or 24 */
+#define ENARF_MAX_JOINTS 32
+
+/* interpolation / padding enums of cuda_extension/triplane_sampler.py:7-16 */
+#define ENARF_INTERP_BILINEAR 0
+#define ENARF_INTERP_NEAREST  1
+#define ENARF_PAD_ZEROS       0
+#define ENARF_PAD_BORDER      1
+#define ENARF_PAD_REFLECTION  2
+
+/* origin_location of libraries/NARF/pose_utils.py:129-148 */
+#define ENARF_ORIGIN_CENTER       0
+#define ENARF_ORIGIN_CENTER_FIXED 1
+#define ENARF_ORIGIN_CENTER_HEAD  2
+
+/* arithmetic of the density/colour MLP (libraries/NeRF/net.py:10-27) */
+#define ENARF_MLP_F32     0   /* v_mfma_f32_16x16x4_f32: exact fp32 products (bitwise an fmaf chain) */
+#define ENARF_MLP_BF16X3  1   /* 3-term split-bf16 on v_mfma_f32_16x16x32_bf16: ~1e-5 relative */
+#define ENARF_MLP_BF16    2   /* plain bf16 operands, fp32 accumulate: ~4e-3 relative */
+
+typedef void *enarf_stream_t;
+
+int         enarf_abi_version(void);
+const char *enarf_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * a1. The TriplaneSampler operator.
+ * Replaces triplane_sampler_cuda.triplane_sampler_forward / _backward
+ * (cuda_extension/TriplaneSampler.cpp:15-24, :26-52; kernels TriplaneSampler_kernel.cu:13-92, :94-229).
+ *   out[b,c,i] = sum_{p in xy,yz,zx} sample(input[b, p*C + c], (grid[b,i,p], grid[b,i,(p+1)%3]))
+ * input (B, 3C, H, W) NCHW, grid (B, n_pts, 3) with n_pts = h*w, out (B, C, n_pts).
+ * Nearest mode keeps the reference's overwrite semantics (kernel.cu:84-86): the last plane (zx) wins.
+ * `workspace` (device, enarf_triplane_sample_workspace_bytes() bytes, may be NULL) lets the operator
+ * re-lay the planes channel-last once per call; without it a slower direct-NCHW kernel runs.
+ * Backward: grad_input (same shape as input) must be zero-filled by the caller, as in the reference
+ * (TriplaneSampler.cpp:33-39); either grad pointer may be NULL (= output_mask false).
+ * --------------------------------------------------------------------------------------------- */
+size_t enarf_triplane_sample_workspace_bytes(int B, int C, int H, int W);
+int enarf_triplane_sample_fwd(const float *input, const float *grid, float *out,
+                              int B, int C, int H, int W, long long n_pts,
+                              int interpolation_mode, int padding_mode, int align_corners,
+                              void *workspace, enarf_stream_t stream);
+int enarf_triplane_sample_bwd(const float *grad_out, const float *input, const float *grid,
+                              float *grad_input, float *grad_grid,
+                              int B, int C, int H, int W, long long n_pts,
+                              int interpolation_mode, int padding_mode, int align_corners,
+                              void *workspace, enarf_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Tri-plane re-layout. The renderer reads the 96 feature channels channel-last,
+ *   feat_cl[b][plane][y][x][32]   (one texel = 128 B = one cache line),
+ * and the 3P one-channel part-probability planes in place from the NCHW tensor (channels 96..).
+ * Replaces the F.pad + permute copy of libraries/triplane/sampling.py:96-97.
+ * tri_nchw (B, 96 + 3P, H, W); feat_cl (B, 3, H, W, 32).
+ * --------------------------------------------------------------------------------------------- */
+int enarf_triplane_pack(const float *tri_nchw, float *feat_cl, int B, int channels_total, int H, int W,
+                        enarf_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Per-call preparation (one small launch): 24 joints -> P part frames, canonical scale, and the
+ * per-image style-modulated, demodulated MLP weights packed in MFMA operand order.
+ * Replaces transform_pose (libraries/NARF/pose_utils.py:129-148), the translation scaling of
+ * render (libraries/NeRF/rendering.py:258-260), canonical_scale (models/narf.py:165) and
+ * ModulatedConv1d's weight path (libraries/custom_stylegan2/net.py:233-243) for the 3 layers of
+ * StyledMLP(32, 64, 4).
+ * --------------------------------------------------------------------------------------------- */
+typedef struct {
+    int B;                      /* images */
+    int num_joints;             /* 24 */
+    int origin_location;        /* ENARF_ORIGIN_* ; P = num_joints - 1 (+1 for CENTER_HEAD) */
+    int style_dim;              /* z_rend width */
+    float coordinate_scale;     /* nerf_params.coordinate_scale */
+    int parents[ENARF_MAX_JOINTS];        /* parent joint ids, parents[0] = -1 (host values) */
+    const float *pose_to_camera;          /* device (B, J, 4, 4) */
+    const float *bone_length;             /* device (B, J-1) */
+    const float *canonical_bone_length;   /* device (P,)  buffer of models/narf.py:119 */
+    const float *z_rend;                  /* device (B, style_dim) */
+    /* StyledMLP parameters, device, in the reference's state-dict shapes:           */
+    const float *conv_weight[3];          /* layers.i.conv.weight            (1, out, in, 1)        */
+    const float *mod_weight[3];           /* layers.i.conv.modulation.weight (in, style_dim)        */
+    const float *mod_bias[3];             /* layers.i.conv.modulation.bias   (in,)                  */
+    const float *bias[3];                 /* layers.i.bias                   (1, out, 1)            */
+    /* outputs */
+    float *parts;                         /* device (B, P, 16): R row-major 9, t*scale 3, can_scale, pad 3 */
+    void  *mlp_pack;                      /* device (B, enarf_mlp_pack_bytes()) */
+} enarf_prepare_args;
+
+size_t enarf_mlp_pack_bytes(void);
+int enarf_prepare(const enarf_prepare_args *args, enarf_stream_t stream);
+
+/* Debug/interop helper: unpack the fp32 section of one image's mlp_pack into dense row-major
+ * W1 (64,32), W2 (64,64), W3 (4,64), b1 (64), b2 (64), b3 (4) - 6724 floats (host or device memory
+ * that the host can write is NOT required: `dense` is a device pointer). */
+int enarf_mlp_unpack(const void *mlp_pack_one_image, float *dense, enarf_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a9. The density/colour query on a point cloud.
+ * Replaces TriPlaneNARF.calc_density_and_color_from_camera_coord_v2 (models/narf.py:176-211) with
+ * backbone(mode="weight_feature") (:213-275): bone inverse transform, validity, part probability,
+ * weighted tri-plane feature, StyledMLP, tanh colour, MyReLU*10 density, density *= any_valid.
+ * --------------------------------------------------------------------------------------------- */
+typedef struct {
+    int B; long long N;                   /* points per image */
+    int P;                                /* parts (<= ENARF_MAX_PARTS) */
+    int H, W;                             /* plane resolution (256) */
+    int mlp_mode;                         /* ENARF_MLP_* */
+    int multiply_density_with_weight;     /* nerf_params.multiply_density_with_triplane_wieght */
+    const float *points;                  /* device (B, 3, N) camera coords in the scaled space */
+    const float *parts;                   /* device (B, P, 16) from enarf_prepare */
+    const float *canonical_pose;          /* device (P, 4, 4) buffer of models/narf.py:120 */
+    const float *feat_cl;                 /* device (B or 1, 3, H, W, 32) from enarf_triplane_pack */
+    long long feat_batch_stride;          /* floats between images; 0 = one tri-plane shared by all */
+    const float *mask_planes;             /* device: &tri_nchw[0][96][0][0]; (P*3, H, W) per image */
+    long long mask_batch_stride;          /* floats between images; 0 = shared */
+    const void *mlp_pack;                 /* device (B, enarf_mlp_pack_bytes()) */
+    float *density;                       /* device (B, 1, N) */
+    float *color;                         /* device (B, 3, N), may be NULL */
+    uint32_t *valid_bits;                 /* device (B, N), bit k = part k valid; may be NULL */
+    float *dbg_canonical;                 /* device (B, P, 3, N) canonical coords; may be NULL */
+    float *dbg_weight;                    /* device (B, P, N) part probability (0.125 where invalid); may be NULL */
+} enarf_query_args;
+
+int enarf_query_fwd(const enarf_query_args *args, enarf_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a13. The fused ray march: one wavefront per ray.
+ * Replaces render (libraries/NeRF/rendering.py:227-359) = decide_frustrum_range (:10-79) +
+ * coarse_sample (:82-135) + coarse_to_fine_sample (:138-224) + two density/colour queries + alpha
+ * compositing (:307-335), including the batch-global near/far planes (:15-17) and, when
+ * drop_invalid_rays, the B == 1 removal of rays that hit no cube (:107-110, :337-350).
+ * --------------------------------------------------------------------------------------------- */
+typedef struct {
+    int B, n;                             /* images, rays per image */
+    int P, Nc, Nf;                        /* parts, coarse / fine samples per ray (each <= 64) */
+    int H, W;
+    int mlp_mode;
+    int multiply_density_with_weight;
+    int drop_invalid_rays;                /* the reference does this iff batchsize == 1 */
+    float render_scale;
+    float early_stop_eps;                 /* 0 = exact; > 0 skips MLP work once transmittance < eps */
+    const float *image_coord;             /* device (B, 3, n) homogeneous pixel coords */
+    const float *inv_intrinsics;          /* device (B, 3, 3) */
+    const float *parts;                   /* device (B, P, 16) */
+    const float *canonical_pose;          /* device (P, 4, 4) */
+    const float *feat_cl; long long feat_batch_stride;
+    const float *mask_planes; long long mask_batch_stride;
+    const void *mlp_pack;
+    const float *bins;                    /* device (B, n, Nf) sorted importance samples in [0,1); NULL = draw
+                                             them in-kernel (Philox, `seed`), as rendering.py:192-197 */
+    uint64_t seed;
+    /* outputs */
+    float *color;                         /* device (B, 3, n) */
+    float *mask;                          /* device (B, n) */
+    float *disparity;                     /* device (B, n) */
+    float *fine_weights;                  /* device (B, n, Nf-1) or NULL   (buffers_tensors["fine_weights"]) */
+    float *fine_depth;                    /* device (B, n, Nf)   or NULL   (buffers_tensors["fine_depth"]) */
+    /* parity taps, NULL in production */
+    float *dbg_depth_min, *dbg_depth_max; /* (B, n) */
+    uint8_t *dbg_ray_valid;               /* (B, n) */
+    float *dbg_coarse_density;            /* (B, n, Nc) */
+    float *dbg_fine_density;              /* (B, n, Nf) */
+    float *dbg_fine_color;                /* (B, 3, n, Nf) */
+    uint32_t *dbg_fine_valid;             /* (B, n, Nf) bit masks */
+    float *dbg_bins;                      /* (B, n, Nf) the bins actually used */
+    unsigned long long *counters;         /* [0] valid (part,point) pairs sampled, [1] MLP tiles of 16 points run,
+                                             [2] rays marched; atomically accumulated; NULL = not counted */
+} enarf_render_args;
+
+int enarf_render_fwd(const enarf_render_args *args, enarf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ENARF_HIP_H */

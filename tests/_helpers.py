@@ -1,0 +1,85 @@
+"""Shared set-up of the parity tests: one synthetic scene -> oracle inputs (CPU) and device inputs (GPU)."""
+import os
+
+import numpy as np
+import torch
+
+from enarf_gan_amd import synth
+from oracle import enarf_oracle as O
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_golden(name):
+    return dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
+
+
+class Scene:
+    """CPU-side inputs of the oracle for one synthetic scene."""
+
+    def __init__(self, size, batch, origin_location="center_fixed", style_dim=256, **kw):
+        self.raw = synth.make_scene(size, batch, origin_location, style_dim, **kw)
+        s = self.raw
+        self.B, self.ol, self.cs = batch, origin_location, 3.0
+        self.pose_parts, self.bl_parts = O.transform_pose(s["pose_to_camera"], s["bone_length"], origin_location,
+                                                          s["parents"])
+        self.cpose, self.cbl = O.register_canonical_pose(s["canonical_pose"], s["parents"], origin_location)
+        self.pose_scaled = O.scale_pose_translation(self.pose_parts, self.cs)
+        self.scale = O.canonical_scale(self.cbl, self.bl_parts, self.cs)
+        self.P = self.pose_parts.shape[1]
+
+    def weights(self):
+        return O.modulated_weights(self.raw["mlp"], self.raw["z_rend"])
+
+    def oracle_render(self, coord, Nc, Nf, bins, dtype=torch.float32, taps=True):
+        s = self.raw
+        return O.render(coord.to(dtype), self.pose_parts, self.bl_parts, s["inv_intrinsics"], self.cpose, self.cbl,
+                        s["tri_plane"], s["mlp"], s["z_rend"], self.cs, Nc, Nf, bins=bins, return_taps=taps)
+
+
+class DeviceScene:
+    """The same scene prepared for the HIP path (enarf_prepare + enarf_triplane_pack)."""
+
+    def __init__(self, sc: Scene, device="cuda:0"):
+        from enarf_gan_amd import ops
+        s = sc.raw
+        d = torch.device(device)
+        self.sc, self.dev = sc, d
+        self.tri = s["tri_plane"].to(d).contiguous()
+        self.feat_cl = ops.triplane_pack(self.tri)
+        self.mlp = {k: v.to(d) for k, v in s["mlp"].items()}
+        self.cpose = sc.cpose.to(d)
+        self.parts, self.pack = ops.prepare(s["pose_to_camera"].to(d), s["bone_length"].to(d), sc.cbl.to(d),
+                                            s["z_rend"].to(d), self.mlp, s["parents"], sc.ol, sc.cs)
+        self.inv_K = s["inv_intrinsics"].to(d)
+
+    def render(self, coord, Nc, Nf, bins=None, **kw):
+        from enarf_gan_amd import ops
+        b = None if bins is None else bins.to(self.dev)
+        return ops.render_fwd(coord.to(self.dev), self.inv_K, self.parts, self.cpose, self.tri, self.feat_cl,
+                              self.pack, Nc, Nf, bins=b, **kw)
+
+    def query(self, pts, **kw):
+        from enarf_gan_amd import ops
+        return ops.query_fwd(pts.to(self.dev), self.parts, self.cpose, self.tri, self.feat_cl, self.pack, **kw)
+
+
+def bits_of(valid_bool):
+    """(B,P,...) bool tensor -> (B,...) uint32 numpy bit masks."""
+    v = valid_bool.numpy().astype(np.uint32)
+    P = v.shape[1]
+    sh = np.arange(P, dtype=np.uint32).reshape((1, P) + (1,) * (v.ndim - 2))
+    return (v << sh).sum(axis=1).astype(np.uint32)
+
+
+def rel_err(ours, ref):
+    ours = np.asarray(ours, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    return np.abs(ours - ref) / max(np.abs(ref).max(), 1e-6)
+
+
+def assert_close(ours, ref, what, rtol=1e-4, frac_ok=0.0):
+    e = rel_err(ours, ref)
+    bad = float((e > rtol).mean()) if e.size else 0.0
+    assert bad <= frac_ok, f"{what}: max rel err {e.max():.3e}, {bad * 100:.4f}% of elements above {rtol}"
+    return float(e.max()) if e.size else 0.0

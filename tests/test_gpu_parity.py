@@ -1,0 +1,291 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the oracle and the reference goldens.
+
+Floating point: <= 1e-4 relative to the tensor's scale (the north-star bound) for mlp modes f32 and
+bf16x3; validity bit masks, ray validity and depth ranges bit-exact against the oracle.
+"""
+import numpy as np
+import pytest
+import torch
+
+from _helpers import DeviceScene, Scene, assert_close, bits_of, load_golden, rel_err
+from oracle import enarf_oracle as O
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from enarf_gan_amd import ops as _ops
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    return _ops
+
+
+def _cpu(t):
+    return t.detach().cpu()
+
+
+# --------------------------------------------------------------------------------------------- prepare / pack
+@pytest.mark.parametrize("ol,style_dim,B", [("center_fixed", 256, 2), ("center+head", 20, 1), ("center", 20, 3)])
+def test_prepare_matches_oracle(ops, ol, style_dim, B):
+    sc = Scene(32, B, ol, style_dim)
+    ds = DeviceScene(sc)
+    parts = _cpu(ds.parts)
+    R = sc.pose_scaled[:, :, :3, :3].reshape(B, sc.P, 9)
+    t = sc.pose_scaled[:, :, :3, 3]
+    assert torch.equal(parts[:, :, :9], R), "part rotations must be copied exactly"
+    assert torch.equal(parts[:, :, 9:12], t), "scaled part translations must be bit-exact"
+    assert torch.equal(parts[:, :, 12], sc.scale), "canonical scale must be bit-exact"
+    ref_w = sc.weights()
+    for b in range(B):
+        W1, W2, W3, b1, b2, b3 = [_cpu(x) for x in ops.mlp_unpack(ds.pack[b])]
+        for ours, (w, bias) in zip(((W1, b1), (W2, b2), (W3, b3)), ref_w):
+            assert_close(ours[0], w[b], "modulated weight", 2e-6)
+            assert torch.equal(ours[1], bias)
+
+
+def test_triplane_pack_is_a_pure_permutation(ops):
+    sc = Scene(32, 2)
+    tri = sc.raw["tri_plane"].cuda()
+    cl = _cpu(ops.triplane_pack(tri))
+    ref = sc.raw["tri_plane"][:, :96].reshape(2, 3, 32, 256, 256).permute(0, 1, 3, 4, 2)
+    assert torch.equal(cl, ref)
+
+
+# --------------------------------------------------------------------------------------------- a1 operator
+def test_sampler_golden_fwd_bwd(ops):
+    g = load_golden("sampler_b2")
+    inp = torch.from_numpy(g["input"]).cuda()
+    pos = torch.from_numpy(g["position"]).cuda()
+    grid = pos.permute(0, 2, 1)[:, :, None, :].contiguous()
+    out = ops.triplane_sample_fwd(inp, grid)
+    assert_close(_cpu(out)[..., 0], g["output"], "sampler fwd", 1e-5)
+    go = torch.from_numpy(g["grad_output"]).cuda()[..., None].contiguous()
+    gi, gg = ops.triplane_sample_bwd(go, inp, grid, 0, 0, False, True, True)
+    assert_close(_cpu(gi), g["grad_input"], "sampler grad_input", 1e-5)
+    assert_close(_cpu(gg)[:, :, 0].permute(0, 2, 1), g["grad_position"], "sampler grad_grid", 1e-5)
+
+
+@pytest.mark.parametrize("C", [32, 8, 5])
+def test_sampler_fast_path_vs_oracle(ops, C):
+    g = torch.Generator().manual_seed(C)
+    inp = torch.randn(2, 3 * C, 40, 56, generator=g)
+    grid = torch.rand(2, 777, 1, 3, generator=g) * 2.2 - 1.1
+    ref = O.triplane_sampler_forward(inp, grid)
+    for ws in (True, False):
+        out = ops.triplane_sample_fwd(inp.cuda(), grid.cuda(), use_workspace=ws)
+        assert_close(_cpu(out), ref, f"sampler fwd C={C} ws={ws}", 1e-5)
+
+
+@pytest.mark.parametrize("pad,align", [(1, False), (2, False), (0, True), (2, True)])
+def test_sampler_padding_modes_vs_torch(ops, pad, align):
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(9)
+    C = 8
+    inp = torch.randn(1, 3 * C, 20, 24, generator=g)
+    grid = torch.rand(1, 300, 1, 3, generator=g) * 3.0 - 1.5
+    mode = ["zeros", "border", "reflection"][pad]
+    ref = 0
+    for p in range(3):
+        g2 = torch.stack([grid[..., p], grid[..., (p + 1) % 3]], dim=-1)
+        ref = ref + F.grid_sample(inp[:, p * C:(p + 1) * C], g2, padding_mode=mode, align_corners=align)
+    for ws in (True, False):
+        out = ops.triplane_sample_fwd(inp.cuda(), grid.cuda(), 0, pad, align, use_workspace=ws)
+        assert_close(_cpu(out), ref, f"pad={mode} align={align}", 1e-5)
+
+
+def test_sampler_nearest_last_plane_wins(ops):
+    g = torch.Generator().manual_seed(4)
+    C = 4
+    inp = torch.randn(1, 3 * C, 16, 16, generator=g)
+    grid = torch.rand(1, 100, 1, 3, generator=g) * 1.9 - 0.95
+    out = _cpu(ops.triplane_sample_fwd(inp.cuda(), grid.cuda(), 1, 0, False))
+    ix = torch.round(((grid[0, :, 0, 2] + 1) * 16 - 1) / 2).long()
+    iy = torch.round(((grid[0, :, 0, 0] + 1) * 16 - 1) / 2).long()
+    ok = (ix >= 0) & (ix < 16) & (iy >= 0) & (iy < 16)
+    ref = inp[0, 2 * C:, iy.clamp(0, 15), ix.clamp(0, 15)] * ok
+    assert torch.allclose(out[0, :, :, 0], ref)
+
+
+# --------------------------------------------------------------------------------------------- a9 query
+@pytest.mark.parametrize("name", ["query_b2_p23", "query_b1_p24"])
+@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
+def test_query_vs_oracle_and_golden(ops, name, mode):
+    g = load_golden(name)
+    sc = Scene(64, int(g["batch"]), str(g["origin_location"]), int(g["style_dim"]))
+    ds = DeviceScene(sc)
+    pts = torch.from_numpy(g["points"])
+    den, col, vb, dc, dw = ds.query(pts, mlp_mode=mode, debug=True)
+    oden, ocol, ovalid, taps = O.query(pts, sc.pose_scaled, sc.scale, sc.cpose, sc.raw["tri_plane"], sc.weights(),
+                                       return_taps=True)
+    obits = bits_of(ovalid)
+    ours_bits = _cpu(vb).numpy().view(np.uint32)
+    assert np.array_equal(ours_bits, obits), "validity bit masks must be bit-exact vs the oracle"
+    assert torch.equal(_cpu(dc), taps["canonical"]), "canonical coordinates must be bit-exact vs the oracle"
+    assert_close(_cpu(dw), taps["weight"], "part probability", 1e-5)
+    assert_close(_cpu(den), oden, "density vs oracle", RTOL)
+    assert_close(_cpu(col), ocol, "colour vs oracle", RTOL)
+    # against the reference's own outputs (same points; masks equal except ulp-on-a-face pairs)
+    same = ours_bits == g["valid"]
+    assert (~same).sum() <= 2
+    assert_close(_cpu(den).numpy()[:, 0][same], g["density"][:, 0][same], "density vs reference", RTOL)
+    assert_close(_cpu(col).numpy().transpose(0, 2, 1)[same], g["color"].transpose(0, 2, 1)[same],
+                 "colour vs reference", RTOL)
+
+
+def test_query_bf16_mode_is_close(ops):
+    g = load_golden("query_b2_p23")
+    sc = Scene(64, 2, "center_fixed", 256)
+    ds = DeviceScene(sc)
+    pts = torch.from_numpy(g["points"])
+    d32, c32 = ds.query(pts, mlp_mode="f32")
+    d16, c16 = ds.query(pts, mlp_mode="bf16")
+    assert rel_err(_cpu(d16), _cpu(d32)).max() < 3e-2
+    assert rel_err(_cpu(c16), _cpu(c32)).max() < 3e-2
+
+
+def test_query_ragged_and_empty(ops):
+    sc = Scene(32, 1, "center_fixed", 20)
+    ds = DeviceScene(sc)
+    g = torch.Generator().manual_seed(0)
+    for N in (1, 63, 65, 1025):
+        pts = (sc.pose_scaled[0, 5, :3, 3][None, :, None] + torch.randn(1, 3, N, generator=g) * 0.5)
+        den, col = ds.query(pts)
+        oden, ocol, _ = O.query(pts, sc.pose_scaled, sc.scale, sc.cpose, sc.raw["tri_plane"], sc.weights())
+        assert_close(_cpu(den), oden, f"density N={N}")
+        assert_close(_cpu(col), ocol, f"colour N={N}")
+    den, col = ds.query(torch.zeros(1, 3, 0))
+    assert den.shape == (1, 1, 0)
+
+
+def test_query_multiply_density_with_weight(ops):
+    sc = Scene(32, 1, "center_fixed", 20)
+    ds = DeviceScene(sc)
+    g = torch.Generator().manual_seed(1)
+    pts = (sc.pose_scaled[0, 2, :3, 3][None, :, None] + torch.randn(1, 3, 2000, generator=g) * 0.6)
+    den, _ = ds.query(pts, multiply_density_with_weight=True)
+    oden, _, _ = O.query(pts, sc.pose_scaled, sc.scale, sc.cpose, sc.raw["tri_plane"], sc.weights(),
+                         multiply_density_with_weight=True)
+    assert_close(_cpu(den), oden, "density * max weight")
+
+
+# --------------------------------------------------------------------------------------------- a13 render
+RENDER_CASES = ["render_c0_64_b1", "render_c1_128_b1_p23", "render_c1_128_b1_p24", "render_gan_32_b2"]
+
+
+def _render_case(name):
+    g = load_golden(name)
+    sc = Scene(int(g["size"]), int(g["batch"]), str(g["origin_location"]), int(g["style_dim"]))
+    idx = torch.from_numpy(g["ray_idx"].astype(np.int64))
+    coord = torch.gather(sc.raw["image_coord"], 3, idx[:, None, None, :].expand(-1, 1, 3, -1)).contiguous()
+    return g, sc, coord, torch.from_numpy(g["bins"])
+
+
+@pytest.mark.parametrize("name", RENDER_CASES)
+@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
+def test_render_vs_oracle_and_golden(ops, name, mode):
+    g, sc, coord, bins = _render_case(name)
+    Nc, Nf, B = int(g["Nc"]), int(g["Nf"]), int(g["batch"])
+    ds = DeviceScene(sc)
+    out = ds.render(coord, Nc, Nf, bins, mlp_mode=mode, debug=True)
+    rc, rm, rd, taps = sc.oracle_render(coord, Nc, Nf, bins)
+    t = {k: _cpu(v) for k, v in out.taps.items()}
+    # integer / boolean work: bit-exact against the oracle
+    assert np.array_equal(t["ray_validity"].numpy().astype(bool), taps["ray_validity"].numpy())
+    assert torch.equal(t["depth_min"], taps["depth_min"]) and torch.equal(t["depth_max"], taps["depth_max"])
+    live = taps["ray_validity"].numpy() if B == 1 else np.ones((B, coord.shape[-1]), dtype=bool)
+    ours_bits = t["fine_valid"].numpy().view(np.uint32)
+    assert np.array_equal(ours_bits[live], bits_of(taps["fine_valid"])[live]), "fine-sample validity masks"
+    assert_close(t["coarse_density"].numpy()[live], taps["coarse_density"].numpy()[live], "coarse density")
+    assert_close(t["fine_density"].numpy()[live], taps["fine_density"].numpy()[live], "fine density")
+    assert_close(_cpu(out.fine_depth)[:, 0].numpy()[live], taps["fine_depth"].numpy()[live], "fine depth", 1e-6)
+    assert_close(_cpu(out.fine_weights)[:, 0].numpy()[live], taps["fine_weights"].numpy()[live], "fine weights")
+    assert_close(_cpu(out.color), rc, "colour vs oracle")
+    assert_close(_cpu(out.mask), rm, "mask vs oracle")
+    assert_close(_cpu(out.disparity), rd, "disparity vs oracle")
+    # the reference's own outputs
+    assert np.array_equal(t["ray_validity"].numpy().astype(bool), g["ray_validity"])
+    assert_close(_cpu(out.color), g["color"], "colour vs reference", frac_ok=2e-3)
+    assert_close(_cpu(out.mask), g["mask"], "mask vs reference", frac_ok=2e-3)
+    assert_close(_cpu(out.disparity), g["disparity"], "disparity vs reference", frac_ok=2e-3)
+    if B == 1:   # dropped rays are exact zeros (rendering.py:337-350)
+        dead = ~g["ray_validity"][0]
+        assert float(_cpu(out.mask)[0][dead].abs().max()) == 0.0 and float(_cpu(out.color)[0][:, dead].abs().max()) == 0.0
+    # integer foreground mask (ENARF_GAN_demo.py:79) away from quantisation steps
+    frac = (g["mask"].astype(np.float64) * 255) % 1.0
+    safe = (frac > 1e-2) & (frac < 1 - 1e-2)
+    assert np.array_equal((_cpu(out.mask).numpy() * 255).astype(np.uint8)[safe], (g["mask"] * 255).astype(np.uint8)[safe])
+
+
+def test_render_production_path_no_debug_matches_debug(ops):
+    g, sc, coord, bins = _render_case("render_c1_128_b1_p23")
+    ds = DeviceScene(sc)
+    a = ds.render(coord, 48, 64, bins, debug=True)
+    b = ds.render(coord, 48, 64, bins, debug=False, want_fine=False)
+    assert torch.equal(a.color, b.color) and torch.equal(a.mask, b.mask) and torch.equal(a.disparity, b.disparity)
+
+
+def test_render_in_kernel_sampling_replays_through_oracle(ops):
+    """bins=None: the kernel draws its own importance samples; feeding the bins it reports to the oracle
+    must reproduce its image, and the bins must be a sorted sample of [0, 1)."""
+    g, sc, coord, _ = _render_case("render_c0_64_b1")
+    ds = DeviceScene(sc)
+    out = ds.render(coord, 48, 32, None, seed=99, debug=True, count=True)
+    kb = _cpu(out.taps["bins"])
+    live = g["ray_validity"][0]
+    kbl = kb[0][torch.from_numpy(live)]
+    assert float(kbl.min()) >= 0.0 and float(kbl.max()) < 1.0
+    assert bool((kbl[:, 1:] >= kbl[:, :-1]).all())
+    rc, rm, rd = sc.oracle_render(coord, 48, 32, kb, taps=False)
+    assert_close(_cpu(out.color), rc, "colour, replayed bins")
+    assert_close(_cpu(out.mask), rm, "mask, replayed bins")
+    out2 = ds.render(coord, 48, 32, None, seed=99)
+    assert torch.equal(out.color, out2.color), "same seed must reproduce"
+    out3 = ds.render(coord, 48, 32, None, seed=100)
+    assert not torch.equal(out.color, out3.color)
+    # importance sampling concentrates bins where the coarse weights are: compare with a uniform draw
+    cnt = _cpu(out.counters).numpy()
+    assert cnt[2] == int(live.sum()) and cnt[0] > 0 and cnt[1] > 0
+
+
+def test_render_counters_match_oracle_pair_count(ops):
+    g, sc, coord, bins = _render_case("render_c0_64_b1")
+    ds = DeviceScene(sc)
+    out = ds.render(coord, 48, 32, bins, count=True)
+    _, _, _, taps = sc.oracle_render(coord, 48, 32, bins)
+    live = taps["ray_validity"][0]
+    cv = taps["coarse_valid"][0][:, live]          # (P, m', Nc)
+    fv = taps["fine_valid"][0][:, live][..., :-1]  # the last fine sample is never queried in production
+    assert int(_cpu(out.counters)[0]) == int(cv.sum() + fv.sum())
+
+
+def test_render_full_image_properties(ops):
+    """Full 128x128 frame (BASELINE config C1): size-independent properties."""
+    sc = Scene(128, 1, "center_fixed", 20)
+    ds = DeviceScene(sc)
+    coord = sc.raw["image_coord"]
+    out = ds.render(coord, 48, 64, None, seed=5, debug=True)
+    m, c = _cpu(out.mask)[0], _cpu(out.color)[0]
+    rv = _cpu(out.taps["ray_validity"])[0].bool()
+    assert torch.isfinite(m).all() and torch.isfinite(c).all() and torch.isfinite(_cpu(out.disparity)).all()
+    assert float(m.min()) >= 0.0 and float(m.max()) <= 1.0 + 1e-5
+    assert float(c.abs().max()) <= 1.0 + 1e-5
+    assert float(m[~rv].abs().max()) == 0.0
+    assert 0.3 < float(rv.float().mean()) < 0.7
+    assert_close(_cpu(out.fine_weights)[0, 0].sum(-1), m, "sum of fine weights == mask", 1e-5)
+    # rays are independent: any subset rendered alone gives bit-identical pixels (given the same bins)
+    kb = out.taps["bins"]
+    idx = torch.arange(5000, 5000 + 777)
+    sub = ds.render(coord[..., idx], 48, 64, _cpu(kb)[:, idx])
+    assert torch.equal(_cpu(sub.mask)[0], m[idx])
+    # oracle on a slice of the full frame
+    sl = torch.arange(64 * 128 + 40, 64 * 128 + 40 + 48)
+    rc, rm, rd = sc.oracle_render(coord[..., sl], 48, 64, _cpu(kb)[:, sl], taps=False)
+    assert_close(m[sl][None], rm, "mask slice vs oracle")
+
+
+def test_render_rejects_unsupported(ops):
+    sc = Scene(32, 1, "center_fixed", 20)
+    ds = DeviceScene(sc)
+    with pytest.raises(NotImplementedError):
+        ds.render(sc.raw["image_coord"], 72, 96, None)

@@ -61,6 +61,8 @@ def test_query_matches_reference(golden_dir, name):
     pose_s = O.scale_pose_translation(pose_p, 3.0)
     scale = O.canonical_scale(cbl, bl_p, 3.0)
     weights = O.modulated_weights(scene["mlp"], scene["z_rend"])
+    NP = 1536                                    # points are independent: a prefix keeps the CPU suite short
+    g = {k: (v[..., :NP] if k in ("points", "density", "color", "valid", "weight") else v) for k, v in g.items()}
     pts = torch.from_numpy(g["points"])
     den, col, valid, taps = O.query(pts, pose_s, scale, cpose, scene["tri_plane"], weights, return_taps=True)
     ours_bits = (valid.numpy().astype(np.uint32) <<
