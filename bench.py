@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""bench.py - rendered rays/s of the fused HIP ray march on synthetic 128x128 frames.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched with
+torch.distributed.run, one rank per GPU. One step = one pass of the hot path over one batch of rays that
+is already resident in HBM: enarf_prepare (part frames + modulated MLP weights) -> enarf_triplane_pack
+(NCHW -> channel-last feature planes) -> enarf_render_fwd (the fused ray march, in-kernel importance
+sampling). Rank 0 prints ONE JSON line. Weak scaling: every rank renders its own frame(s); the path
+has no exchange step, so there is no data-path collective.
+
+Workload = BASELINE.json configs[1]: 128x128 rays, Nc 48 + Nf 64 samples/ray, 24 SMPL joints (P = 23
+parts, `center_fixed`), one frame per GPU per step, fp32 tri-plane, constant (DSO-style) tri-plane.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+BF16_DENSE_TFLOPS = 2500.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--size", type=int, default=128)
+    ap.add_argument("--batch", type=int, default=1, help="frames per GPU per step")
+    ap.add_argument("--nc", type=int, default=48)
+    ap.add_argument("--nf", type=int, default=64)
+    ap.add_argument("--origin", default="center_fixed", choices=["center", "center_fixed", "center+head"])
+    ap.add_argument("--mlp-mode", default="f16x3", choices=["f32", "f16x3", "bf16x3", "bf16"])
+    ap.add_argument("--style-dim", type=int, default=20)
+    ap.add_argument("--cache-triplane", action="store_true",
+                    help="re-lay the (constant) tri-plane once instead of every step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rays", type=int, default=256, help="rays of the same frame timed on the host cores")
+    return ap.parse_args()
+
+
+def cpu_baseline(scene_cpu, Nc, Nf, n_rays):
+    """The oracle (a port of the reference's pure-PyTorch path, F.grid_sample form) on the host cores."""
+    from oracle import enarf_oracle as O
+    s = scene_cpu
+    cores = min(os.cpu_count() or 1, 16)      # the GPU box's CPU share for one GPU is 16 cores
+    torch.set_num_threads(cores)
+    pose_p, bl_p = O.transform_pose(s["pose_to_camera"], s["bone_length"], s["origin_location"], s["parents"])
+    cpose, cbl = O.register_canonical_pose(s["canonical_pose"], s["parents"], s["origin_location"])
+    n = s["image_coord"].shape[-1]
+    # a horizontal band through the middle of the frame (hits and misses mixed, like the full frame)
+    start = (n // 2) - n_rays // 2
+    coord = s["image_coord"][..., start:start + n_rays].contiguous()
+    g = torch.Generator().manual_seed(0)
+    t0 = time.perf_counter()
+    O.render(coord, pose_p, bl_p, s["inv_intrinsics"], cpose, cbl, s["tri_plane"], s["mlp"], s["z_rend"],
+             s["coordinate_scale"], Nc, Nf, generator=g, use_grid_sample=True)
+    dt = time.perf_counter() - t0
+    return {"value": n_rays / dt, "unit": "rays/s", "cores": cores, "kind": "port",
+            "sample": f"{n_rays} consecutive rays of the same frame (middle band), one pass, {dt:.1f} s; "
+                      "oracle/enarf_oracle.py render() with F.grid_sample"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU path in enarf_gan_amd")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from enarf_gan_amd import ops, synth
+    from oracle import enarf_oracle as O   # only for the canonical-pose buffers of the synthetic scene and the cpu_baseline leg
+
+    S, B, Nc, Nf = args.size, args.batch, args.nc, args.nf
+    sc = synth.make_scene(S, B, args.origin, args.style_dim, pose_seed=1234 + 100 * rank, shared_triplane=True)
+    n = S * S
+    P = sc["num_parts"]
+    cpose, cbl = O.register_canonical_pose(sc["canonical_pose"], sc["parents"], args.origin)
+    d = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in sc.items()}
+    tri = sc["tri_plane"][:1].contiguous().to(dev)          # one constant tri-plane shared by the batch (DSO style)
+    mlp = {k: v.to(dev) for k, v in sc["mlp"].items()}
+    cpose_d, cbl_d = cpose.to(dev), cbl.to(dev)
+    coord = d["image_coord"].reshape(B, 3, n).contiguous()
+    feat_cl = torch.empty(1, 3, 256, 256, 32, device=dev)
+    parts = torch.empty(B, P, 16, device=dev)
+    pack = torch.empty(B, ops.mlp_pack_bytes(), dtype=torch.uint8, device=dev)
+    ops.triplane_pack(tri, feat_cl)
+
+    def step(i, count=False):
+        ops.prepare(d["pose_to_camera"], d["bone_length"], cbl_d, d["z_rend"], mlp, sc["parents"], args.origin,
+                    3.0, parts_out=parts, pack_out=pack)
+        if not args.cache_triplane:
+            ops.triplane_pack(tri, feat_cl)
+        return ops.render_fwd(coord, d["inv_intrinsics"], parts, cpose_d, tri, feat_cl, pack, Nc, Nf,
+                              seed=99 + i, mlp_mode=args.mlp_mode, want_fine=True, count=count)
+
+    # algorithmic work of one step, counted by the kernel itself in an untimed pass (same inputs, same seed)
+    cnt = step(0, count=True).counters
+    torch.cuda.synchronize()
+    V, tiles, rays_marched = [int(x) for x in cnt[:3].tolist()]
+
+    for i in range(args.warmup):
+        step(i)
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ops.prepare(d["pose_to_camera"], d["bone_length"], cbl_d, d["z_rend"], mlp, sc["parents"], args.origin,
+                    3.0, parts_out=parts, pack_out=pack)
+        if not args.cache_triplane:
+            ops.triplane_pack(tri, feat_cl)
+        ev0[i].record()
+        ops.render_fwd(coord, d["inv_intrinsics"], parts, cpose_d, tri, feat_cl, pack, Nc, Nf, seed=99,
+                       mlp_mode=args.mlp_mode, want_fine=True)
+        ev1[i].record()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
+
+    if rank == 0:
+        rays_per_step = world * B * n
+        value = rays_per_step * args.steps / elapsed
+        # V*12*(C+1)*4 gathered texel bytes + each tri-plane once + outputs (+ fine side outputs)
+        alg_bytes = V * 1584 + 1 * (96 + 3 * P) * 256 * 256 * 4 + B * n * 20 + B * n * (2 * Nf - 1) * 4
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("render_kernel_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        q = rays_marched * (Nc + Nf - 1)
+        out = {
+            "metric": "rendered rays/sec (128^2, 64 samples/ray, 24 bones)", "value": value, "unit": "rays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"C1: DSO-style {S}x{S} frame, Nc {Nc} + Nf {Nf} samples/ray, 24 joints -> P={P} parts "
+                                   f"({args.origin}), {B} frame/GPU/step, constant fp32 tri-plane 256^2x(96+{3 * P}), "
+                                   f"in-kernel Philox importance sampling",
+                       "mlp_arith": args.mlp_mode, "triplane_relayout_in_step": not args.cache_triplane,
+                       "step": "enarf_prepare + enarf_triplane_pack + enarf_render_fwd"},
+            "roofline": {"bound": "hbm", "kernel": "enarf::render_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                         "valid_part_point_pairs": V, "rays_marched": rays_marched, "mlp_tiles_of_16": tiles,
+                         "mfma_eligible_tflops": q * 12800 / (kern_ms * 1e-3) / 1e12,
+                         "mfma_frac_of_bf16_dense_peak": q * 12800 / (kern_ms * 1e-3) / 1e12 / BF16_DENSE_TFLOPS},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(sc, Nc, Nf, args.cpu_rays)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -9,7 +9,8 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libenarf_hip.so")
+# ENARF_LIB: A/B-test another build of the same ABI (tuning only)
+LIB_PATH = os.environ.get("ENARF_LIB") or os.path.join(_HERE, "csrc", "libenarf_hip.so")
 
 MAX_JOINTS = 32
 MAX_PARTS = 32
@@ -19,7 +20,7 @@ HIDDEN = 64
 INTERP = {"bilinear": 0, "nearest": 1}            # cuda_extension/triplane_sampler.py:7-10
 PADDING = {"zeros": 0, "border": 1, "reflection": 2}   # :12-16
 ORIGIN = {"center": 0, "center_fixed": 1, "center+head": 2}
-MLP_MODE = {"f32": 0, "bf16x3": 1, "bf16": 2}
+MLP_MODE = {"f32": 0, "bf16x3": 1, "bf16": 2, "f16x3": 3}
 
 _f32p = C.c_void_p   # device pointers travel as integers
 

@@ -15,6 +15,7 @@ namespace enarf {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kWave = 64;
 constexpr int kPartStride = 16;
@@ -43,7 +44,8 @@ constexpr int PKH_W1 = 0;                               // [4 ob][hi,lo][64 lane
 constexpr int PKH_W2 = PKH_W1 + 4 * 2 * 64 * 8;         // [4 ob][2 ks][hi,lo][64][8]
 constexpr int PKH_W3 = PKH_W2 + 4 * 2 * 2 * 64 * 8;     // [2 ks][hi,lo][64][8]
 constexpr int PKH_SHORTS = PKH_W3 + 2 * 2 * 64 * 8;     // 14336 shorts = 28672 B
-constexpr size_t kPackBytes = (size_t)PK_F32_FLOATS * 4 + (size_t)PKH_SHORTS * 2;   // 57920 B
+// fp16 section: same layout as the bf16 section, hi = f16(w), lo = f16(w - hi)
+constexpr size_t kPackBytes = (size_t)PK_F32_FLOATS * 4 + (size_t)PKH_SHORTS * 2 * 2;   // 86592 B
 static_assert(kPackBytes % 16 == 0, "pack must stay 16-byte aligned per image");
 
 // ---- wave primitives ----------------------------------------------------------------------------
@@ -182,6 +184,11 @@ __device__ __forceinline__ unsigned short f32_to_bf16_rne(float f) {
     return (unsigned short)(u >> 16);
 }
 __device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
+
+// fp16 with saturation (so that hi stays finite and lo = x - hi carries the rest)
+__device__ __forceinline__ _Float16 f32_to_f16_sat(float f) {
+    return (_Float16)fminf(fmaxf(f, -65504.0f), 65504.0f);
+}
 
 // ---- Philox4x32-10 (counter-based RNG for the importance samples) -----------------------------------
 __device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,

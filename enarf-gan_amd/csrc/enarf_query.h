@@ -13,8 +13,9 @@
 namespace enarf {
 
 struct QueryCtx {
+    int ablate;              // diagnosis-only switches (ENARF_ABLATE), wave-uniform; 0 in production
     const float *mlp;        // LDS: fp32 weights of the MLP pack [PK_W1, PK_B1) (mode F32), else unused
-    const short *mlp_h;      // LDS: bf16 section (modes BF16X3 / BF16), else unused
+    const short *mlp_h;      // LDS: bf16 section (modes BF16X3 / BF16) or fp16 section (F16X3), else unused
     const float *bias;       // LDS: 144 floats = pack[PK_B1, PK_F32_FLOATS): b1[64] b2[64] b3[16]
     const float *parts;      // LDS: P x 16
     const float *canon;      // LDS: P x 12 (Rc row-major, tc)
@@ -168,8 +169,64 @@ __device__ __forceinline__ f32x4 mlp_tile_bf16(const float *__restrict__ Bp, con
     return act4(o);
 }
 
+// split-fp16: same structure, 11-bit halves -> ~2^-21 relative
+__device__ __forceinline__ void split8h(const float v[8], f16x8 &hi, f16x8 &lo) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const _Float16 h = f32_to_f16_sat(v[i]);
+        hi[i] = h;
+        lo[i] = f32_to_f16_sat(v[i] - (float)h);
+    }
+}
+__device__ __forceinline__ f32x4 mma_split_h(const short *__restrict__ Ahl, const f16x8 &bh, const f16x8 &bl, f32x4 c,
+                                             int lane) {
+    const f16x8 ah = *reinterpret_cast<const f16x8 *>(Ahl + lane * 8);
+    const f16x8 al = *reinterpret_cast<const f16x8 *>(Ahl + 512 + lane * 8);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, c, 0, 0, 0);
+    return c;
+}
+__device__ __forceinline__ f32x4 mlp_tile_f16x3(const float *__restrict__ Bp, const short *__restrict__ Hp,
+                                                const float x[8], int lane) {
+    const int g = lane >> 4;
+    f32x4 a1[4], a2[4];
+    f16x8 bh, bl;
+    split8h(x, bh, bl);
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) {
+        a1[ob] = *reinterpret_cast<const f32x4 *>(Bp + 16 * ob + 4 * g);
+        a1[ob] = mma_split_h(Hp + PKH_W1 + ob * 1024, bh, bl, a1[ob], lane);
+        a1[ob] = act4(a1[ob]);
+        a2[ob] = *reinterpret_cast<const f32x4 *>(Bp + 64 + 16 * ob + 4 * g);
+    }
+    f32x4 o = *reinterpret_cast<const f32x4 *>(Bp + 128 + 4 * g);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        float v[8];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) v[jj] = a1[2 * ks + (jj >> 2)][jj & 3];
+        split8h(v, bh, bl);
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob)
+            a2[ob] = mma_split_h(Hp + PKH_W2 + (ob * 2 + ks) * 1024, bh, bl, a2[ob], lane);
+    }
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) a2[ob] = act4(a2[ob]);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        float v[8];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) v[jj] = a2[2 * ks + (jj >> 2)][jj & 3];
+        split8h(v, bh, bl);
+        o = mma_split_h(Hp + PKH_W3 + ks * 1024, bh, bl, o, lane);
+    }
+    return act4(o);
+}
+
 template <int MODE>
 __device__ __forceinline__ f32x4 mlp_tile(const QueryCtx &S, const float x[8], int lane) {
+    if (MODE == ENARF_MLP_F16X3) return mlp_tile_f16x3(S.bias, S.mlp_h, x, lane);
     if (MODE == ENARF_MLP_F32) return mlp_tile_f32(S.mlp, S.bias, x, lane);
     if (MODE == ENARF_MLP_BF16X3) return mlp_tile_bf16<3>(S.bias, S.mlp_h, x, lane);
     return mlp_tile_bf16<1>(S.bias, S.mlp_h, x, lane);
@@ -217,7 +274,7 @@ __device__ __forceinline__ void query_wave(const QueryCtx &S, uint32_t cand, flo
         const uint64_t bal = __ballot(v);
         if (bal == 0) continue;
         float w = 0.0f;
-        if (v) {   // part probability: product over planes of sigmoid(bilinear)  (sampling.py:43-48, :62)
+        if (v && !(S.ablate & 2)) {   // part probability: product over planes of sigmoid(bilinear)  (sampling.py:43-48, :62)
             const float *mp = S.mask + (size_t)(3 * k) * mplane;
             const float s0 = sigmoidf_(sample_scalar_plane(mp, cx, cy, S.H, S.W));
             const float s1 = sigmoidf_(sample_scalar_plane(mp + mplane, cy, cz, S.H, S.W));
@@ -235,7 +292,7 @@ __device__ __forceinline__ void query_wave(const QueryCtx &S, uint32_t cand, flo
             const int src = 16 * t + (lane & 15);
             const float qx = __shfl(cx, src), qy = __shfl(cy, src), qz = __shfl(cz, src);
             const float qw = __shfl(w, src);
-            if ((bal >> src) & 1ull) gather_pair(featg, S.H, S.W, qx, qy, qz, qw, feat[t]);
+            if (((bal >> src) & 1ull) && !(S.ablate & 1)) gather_pair(featg, S.H, S.W, qx, qy, qz, qw, feat[t]);
         }
     }
 
@@ -246,7 +303,7 @@ __device__ __forceinline__ void query_wave(const QueryCtx &S, uint32_t cand, flo
     for (int r = 0; r < 4; ++r) h[r] = 0.0f;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        if (((anyv >> (16 * t)) & 0xFFFFull) == 0) continue;
+        if (((anyv >> (16 * t)) & 0xFFFFull) == 0 || (S.ablate & 4)) continue;
         tiles_run |= (0xFFFFull << (16 * t));
         n_tiles += 1;
         const f32x4 o = mlp_tile<MODE>(S, feat[t], lane);

@@ -2,6 +2,11 @@
 // gfx950 only. See include/enarf_hip.h for the contract and DESIGN.md for the kernel design.
 #include "enarf_query.h"
 #include "enarf_host.h"
+#include <cstdlib>
+
+#ifndef ENARF_RENDER_WAVES_PER_SIMD
+#define ENARF_RENDER_WAVES_PER_SIMD 2
+#endif
 
 namespace enarf {
 
@@ -12,31 +17,32 @@ struct PrepareParams {
     enarf_prepare_args a;
 };
 
+__device__ __forceinline__ void put_split(short *h, float w) {   // h -> bf16 section; + PKH_SHORTS -> fp16 section
+    const unsigned short hi = f32_to_bf16_rne(w);
+    h[0] = (short)hi;
+    h[512] = (short)f32_to_bf16_rne(w - bf16_to_f32(hi));
+    const _Float16 fh = f32_to_f16_sat(w), fl = f32_to_f16_sat(w - (float)fh);
+    h[PKH_SHORTS] = __builtin_bit_cast(short, fh);
+    h[PKH_SHORTS + 512] = __builtin_bit_cast(short, fl);
+}
+
 __device__ __forceinline__ void pack_weight_row(float *__restrict__ pf, short *__restrict__ ph, int layer, int o,
                                                 int c, float w) {
     // see the layout comment in enarf_device.h
     const int ob = o >> 4, i = o & 15;
-    const unsigned short hi = f32_to_bf16_rne(w);
-    const unsigned short lo = f32_to_bf16_rne(w - bf16_to_f32(hi));
     if (layer == 0) {
         const int g = c >> 3, s = c & 7;
         pf[PK_W1 + (ob * 8 + s) * 64 + g * 16 + i] = w;
-        short *h = ph + PKH_W1 + ob * 1024 + (g * 16 + i) * 8 + s;
-        h[0] = (short)hi;
-        h[512] = (short)lo;
+        put_split(ph + PKH_W1 + ob * 1024 + (g * 16 + i) * 8 + s, w);
     } else {
         const int obp = c >> 4, g = (c & 15) >> 2, rp = c & 3;
         const int q = obp * 4 + rp, ks = obp >> 1, jj = (obp & 1) * 4 + rp;
         if (layer == 1) {
             pf[PK_W2 + (ob * 16 + q) * 64 + g * 16 + i] = w;
-            short *h = ph + PKH_W2 + (ob * 2 + ks) * 1024 + (g * 16 + i) * 8 + jj;
-            h[0] = (short)hi;
-            h[512] = (short)lo;
+            put_split(ph + PKH_W2 + (ob * 2 + ks) * 1024 + (g * 16 + i) * 8 + jj, w);
         } else {
             pf[PK_W3 + q * 64 + g * 16 + i] = w;
-            short *h = ph + PKH_W3 + ks * 1024 + (g * 16 + i) * 8 + jj;
-            h[0] = (short)hi;
-            h[512] = (short)lo;
+            put_split(ph + PKH_W3 + ks * 1024 + (g * 16 + i) * 8 + jj, w);
         }
     }
 }
@@ -85,7 +91,7 @@ __global__ __launch_bounds__(256) void prepare_kernel(const PrepareParams prm) {
     float *pf = reinterpret_cast<float *>(reinterpret_cast<char *>(a.mlp_pack) + (size_t)b * kPackBytes);
     short *ph = reinterpret_cast<short *>(pf + PK_F32_FLOATS);
     for (int i = tid; i < PK_F32_FLOATS; i += 256) pf[i] = 0.0f;
-    for (int i = tid; i < PKH_SHORTS; i += 256) ph[i] = 0;
+    for (int i = tid; i < 2 * PKH_SHORTS; i += 256) ph[i] = 0;
     __syncthreads();
     const float *z = a.z_rend + (size_t)b * a.style_dim;
     const float mscale = 1.0f / sqrtf((float)a.style_dim);
@@ -161,7 +167,8 @@ __device__ __forceinline__ void stage_common(float *lds, QueryCtx &S, float *&sc
     scratch = l_canon + P * 12;
     const float *pf = reinterpret_cast<const float *>(pack_b);
     const f32x4 *src4 = (MODE == ENARF_MLP_F32) ? reinterpret_cast<const f32x4 *>(pf)
-                                                : reinterpret_cast<const f32x4 *>(pf + PK_F32_FLOATS);
+                        : (MODE == ENARF_MLP_F16X3) ? reinterpret_cast<const f32x4 *>(pf + PK_F32_FLOATS + PKH_SHORTS / 2)
+                                                    : reinterpret_cast<const f32x4 *>(pf + PK_F32_FLOATS);
     f32x4 *dst4 = reinterpret_cast<f32x4 *>(l_mlp);
     for (int i = tid; i < lds_mlp_floats<MODE>() / 4; i += nthreads) dst4[i] = src4[i];
     for (int i = tid; i < 144; i += nthreads) l_bias[i] = pf[PK_B1 + i];
@@ -206,6 +213,7 @@ __global__ __launch_bounds__(256) void query_kernel(const enarf_query_args a, in
     S.feat = a.feat_cl + (size_t)b * a.feat_batch_stride;
     S.mask = a.mask_planes + (size_t)b * a.mask_batch_stride;
     S.H = a.H; S.W = a.W; S.P = a.P; S.mult_w = a.multiply_density_with_weight;
+    S.ablate = 0;
     __syncthreads();
 
     // colour of a point with no valid part: the reference still runs the MLP on a zero feature
@@ -299,10 +307,13 @@ __device__ __forceinline__ bool ray_hits_part(const float *F, float dx, float dy
 }
 
 template <int MODE>
-__global__ __launch_bounds__(256) void render_kernel(const enarf_render_args a, int wgs_per_image, int rays_per_wg) {
+__global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kernel(const enarf_render_args a, int wgs_per_image, int rays_per_wg,
+                                                                                  int xcd_chunked, int ablate, int ray_strided) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    // Tile mapping. With >= 8 images each XCD takes whole images (their tri-planes stay in that XCD's L2);
+    // with fewer, tiles are dealt round-robin so the dense middle of a frame is spread over all 8 XCDs.
+    const int bid = xcd_chunked ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
     const int b = bid / wgs_per_image, tile = bid % wgs_per_image;
     const int P = a.P, Nc = a.Nc, Nf = a.Nf, n = a.n;
 
@@ -313,6 +324,7 @@ __global__ __launch_bounds__(256) void render_kernel(const enarf_render_args a, 
     S.feat = a.feat_cl + (size_t)b * a.feat_batch_stride;
     S.mask = a.mask_planes + (size_t)b * a.mask_batch_stride;
     S.H = a.H; S.W = a.W; S.P = P; S.mult_w = a.multiply_density_with_weight;
+    S.ablate = ablate;
     float *l_dtab = scratch;          // 32 range-test depths
     float *l_btab = scratch + 32;     // Nc + 1 bin edges (<= 65)
     float *l_red = scratch + 100;     // 8 partials + near/far
@@ -349,8 +361,10 @@ __global__ __launch_bounds__(256) void render_kernel(const enarf_render_args a, 
     const QueryDbg nodbg{nullptr, nullptr, 0, 0};
 
     for (int r = wave; r < rays_per_wg; r += 4) {
-        const int ray = __builtin_amdgcn_readfirstlane(tile * rays_per_wg + r);
-        if (ray >= n) break;
+        // rays are dealt to workgroups with a stride of wgs_per_image: every workgroup gets the same mix of
+        // rays that hit the body and rays that miss, so workgroup run times are even
+        const int ray = __builtin_amdgcn_readfirstlane(ray_strided ? r * wgs_per_image + tile : tile * rays_per_wg + r);
+        if (ray >= n) { if (ray_strided) break; else break; }
         // ---- ray direction K^-1 [u v w]  (rendering.py:26-38)
         const float u = coord[ray], v = coord[n + ray], w = coord[2 * n + ray];
         const float dx = exact_dot3(Ki[0], u, Ki[1], v, Ki[2], w);
@@ -567,7 +581,7 @@ static int check_common(const char *who, int B, int P, int H, int W, int mode, c
                         const void *feat, const void *mask, const void *pack) {
     if (B <= 0 || P <= 0 || P > ENARF_MAX_PARTS) return host::fail(ENARF_ERR_ARG, "%s: bad B=%d or P=%d (max %d parts)", who, B, P, ENARF_MAX_PARTS);
     if (H <= 0 || W <= 0) return host::fail(ENARF_ERR_ARG, "%s: bad plane size %dx%d", who, H, W);
-    if (mode < 0 || mode > 2) return host::fail(ENARF_ERR_ARG, "%s: bad mlp_mode %d", who, mode);
+    if (mode < 0 || mode > 3) return host::fail(ENARF_ERR_ARG, "%s: bad mlp_mode %d", who, mode);
     if (!parts || !canon || !feat || !mask || !pack) return host::fail(ENARF_ERR_ARG, "%s: null input pointer", who);
     return 0;
 }
@@ -583,6 +597,7 @@ extern "C" int enarf_query_fwd(const enarf_query_args *args, enarf_stream_t stre
     switch (a.mlp_mode) {
         case ENARF_MLP_F32: return launch_query<ENARF_MLP_F32>(a, st);
         case ENARF_MLP_BF16X3: return launch_query<ENARF_MLP_BF16X3>(a, st);
+        case ENARF_MLP_F16X3: return launch_query<ENARF_MLP_F16X3>(a, st);
         default: return launch_query<ENARF_MLP_BF16>(a, st);
     }
 }
@@ -594,9 +609,13 @@ static int launch_render(const enarf_render_args &a, hipStream_t st) {
     const long long total = (long long)a.B * a.n;
     int rpw = 64;
     while (rpw > 8 && total / rpw < 4096) rpw >>= 1;
-    const int wgs = (a.n + rpw - 1) / rpw;
     const size_t lds = (size_t)lds_total_floats<MODE>(a.P) * 4;
-    hipLaunchKernelGGL(render_kernel<MODE>, dim3((unsigned)(wgs * a.B)), dim3(256), lds, st, a, wgs, rpw);
+    const char *ab = getenv("ENARF_ABLATE");      // diagnosis only: 1 skip feature gathers, 2 skip mask planes, 4 skip MLP
+    const char *rp = getenv("ENARF_RAYS_PER_WG");
+    if (rp && atoi(rp) > 0) rpw = atoi(rp);
+    const int wgs = (a.n + rpw - 1) / rpw;
+    hipLaunchKernelGGL(render_kernel<MODE>, dim3((unsigned)(wgs * a.B)), dim3(256), lds, st, a, wgs, rpw,
+                       a.B >= 8 ? 1 : 0, ab ? atoi(ab) : 0, getenv("ENARF_NO_STRIDE") ? 0 : 1);
     return host::check_launch("enarf_render_fwd");
 }
 
@@ -618,6 +637,7 @@ extern "C" int enarf_render_fwd(const enarf_render_args *args, enarf_stream_t st
     switch (a.mlp_mode) {
         case ENARF_MLP_F32: return launch_render<ENARF_MLP_F32>(a, st);
         case ENARF_MLP_BF16X3: return launch_render<ENARF_MLP_BF16X3>(a, st);
+        case ENARF_MLP_F16X3: return launch_render<ENARF_MLP_F16X3>(a, st);
         default: return launch_render<ENARF_MLP_BF16>(a, st);
     }
 }

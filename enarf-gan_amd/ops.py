@@ -177,6 +177,15 @@ def query_fwd(points: torch.Tensor, parts: torch.Tensor, canonical_pose: torch.T
     H, W = tri.shape[2], tri.shape[3]
     mstride, fstride = _plane_strides(tri, feat_cl, B)
     dev = pts.device
+    if N == 0:   # nothing to launch (an empty tensor has no device pointer)
+        def z(*shape, dt=torch.float32):
+            return torch.empty(*shape, dtype=dt, device=dev)
+        out = (z(B, 1, 0), z(B, 3, 0) if need_color else None)
+        if need_valid or debug:
+            out = out + (z(B, 0, dt=torch.int32),)
+        if debug:
+            out = out + (z(B, P, 3, 0), z(B, P, 0))
+        return out
     den = torch.empty(B, 1, N, dtype=torch.float32, device=dev)
     col = torch.empty(B, 3, N, dtype=torch.float32, device=dev) if need_color else None
     vb = torch.empty(B, N, dtype=torch.int32, device=dev) if (need_valid or debug) else None

@@ -44,6 +44,8 @@ extern "C" {
 #define ENARF_MLP_F32     0   /* v_mfma_f32_16x16x4_f32: exact fp32 products (bitwise an fmaf chain) */
 #define ENARF_MLP_BF16X3  1   /* 3-term split-bf16 on v_mfma_f32_16x16x32_bf16: ~1e-5 relative */
 #define ENARF_MLP_BF16    2   /* plain bf16 operands, fp32 accumulate: ~4e-3 relative */
+#define ENARF_MLP_F16X3   3   /* 3-term split-fp16 on v_mfma_f32_16x16x32_f16: ~1e-6 relative, same MFMA count as
+                                 BF16X3; operands saturate at +-65504 per half (|x| < 1.3e5 stays finite) */
 
 typedef void *enarf_stream_t;
 
