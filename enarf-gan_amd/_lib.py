@@ -92,6 +92,10 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own HIP runtime (torch/lib/libamdhip64.so). It must be in the process BEFORE this
+    # library is dlopen'ed so that both resolve to ONE runtime; loaded the other way round, this library binds
+    # /opt/rocm's copy and its launches fail with "no ROCm-capable device is detected" next to torch's.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise EnarfHipError(
             f"{LIB_PATH} is missing: build it with `python -m enarf_gan_amd.build` (hipcc, gfx950). "

@@ -1,0 +1,245 @@
+"""TriPlaneNARF with the reference's constructor, method names and state-dict keys (models/narf.py:17-290,
+libraries/NARF/base.py:11-83, libraries/NeRF/base.py:11-151), backed by the HIP kernels.
+
+State-dict keys on the path: `tri_plane`, `mlp.layers.{0,1,2}.{bias, conv.weight,
+conv.modulation.weight, conv.modulation.bias, noise.weight}`, buffers `canonical_pose`,
+`canonical_bone_length`, `canonical_joints`, `canonical_parent_joints` - so reference snapshots load.
+
+Out of scope here: the StyleGAN2-ADA tri-plane generator. With `constant_triplane: False`
+the caller assigns `model.tri_plane_gen = callable(z, encoded_length, truncation_psi=...) -> (B, (32+P)*3, 256, 256)`
+or passes `model_input["tri_plane_feature"]`.
+"""
+import math
+from typing import Dict, List, Optional, Union
+
+import numpy as np
+import torch
+from torch import nn
+
+from .. import ops
+from ..libraries.NARF.pose_utils import transform_pose
+from ..libraries.NeRF.rendering import _parts_from_part_poses, render, render_entire_img
+
+
+# ---- parameter containers mirroring libraries/NeRF/net.py:10-27 and custom_stylegan2/net.py:128-320 ----------
+class _EqualLinearParams(nn.Module):            # EqualLinear(style_dim, in_channel, bias_init=1)
+    def __init__(self, in_dim, out_dim, bias_init=1.0):
+        super().__init__()
+        self.weight = nn.Parameter(torch.randn(out_dim, in_dim))
+        self.bias = nn.Parameter(torch.zeros(out_dim).fill_(bias_init))
+
+
+class _ModulatedConv1dParams(nn.Module):        # ModulatedConv1d(in, out, 1, style_dim)
+    def __init__(self, in_channel, out_channel, style_dim):
+        super().__init__()
+        self.weight = nn.Parameter(torch.randn(1, out_channel, in_channel, 1))
+        self.modulation = _EqualLinearParams(style_dim, in_channel, bias_init=1.0)
+
+
+class _NoiseParams(nn.Module):                  # NoiseInjection (unused on this path: use_noise=False)
+    def __init__(self):
+        super().__init__()
+        self.weight = nn.Parameter(torch.zeros(1))
+
+
+class _StyledConv1dParams(nn.Module):           # StyledConv(..., conv_1d=True, use_noise=False)
+    def __init__(self, in_channel, out_channel, style_dim):
+        super().__init__()
+        self.conv = _ModulatedConv1dParams(in_channel, out_channel, style_dim)
+        self.bias = nn.Parameter(torch.zeros(1, out_channel, 1))
+        self.noise = _NoiseParams()
+
+
+class StyledMLP(nn.Module):
+    """Parameters of StyledMLP(in_dim, hidden_dim, out_dim, style_dim, num_layers=3); evaluated inside the HIP kernels."""
+
+    def __init__(self, in_dim, hidden_dim, out_dim, style_dim=512, num_layers=3):
+        super().__init__()
+        assert (in_dim, hidden_dim, out_dim, num_layers) == (32, 64, 4, 3), \
+            "the HIP kernels implement StyledMLP(32, 64, 4), the only shape the tri-plane NARF uses (narf.py:77)"
+        self.layers = nn.ModuleList([_StyledConv1dParams(in_dim, hidden_dim, style_dim),
+                                     _StyledConv1dParams(hidden_dim, hidden_dim, style_dim),
+                                     _StyledConv1dParams(hidden_dim, out_dim, style_dim)])
+        self.hidden_dim = hidden_dim
+
+    def as_dict(self) -> Dict[str, torch.Tensor]:
+        return {k: v for k, v in self.state_dict(keep_vars=True).items()}
+
+
+class TriPlaneNARF(nn.Module):
+    def __init__(self, config, z_dim: Union[int, List[int]] = 256, num_bone=1, bone_length=True, parent=None,
+                 num_bone_param=None, view_dependent: bool = False):
+        super().__init__()
+        assert bone_length
+        assert hasattr(config, "origin_location")
+        if view_dependent:
+            raise NotImplementedError("view-dependent colour (no_ray_direction: False) is not on the shipped tri-plane "
+                                      "path (configs set no_ray_direction: True / GAN) and is not implemented")
+        for flag in ("selector_mlp", "no_selector", "clamp_mask"):
+            if getattr(config, flag, False):
+                raise NotImplementedError(f"nerf_params.{flag}=True is not implemented by the HIP kernels")
+        self.config = config
+        self.tri_plane_based = True
+        self.w_dim, self.feat_dim = 512, 32
+        self.origin_location = config.origin_location
+        self.coordinate_scale = config.coordinate_scale
+        assert self.origin_location in ["center", "center_fixed", "center+head"]
+        if isinstance(z_dim, list):
+            self.z_dim, self.z2_dim = z_dim[0], z_dim[1]
+        else:
+            self.z_dim = self.z2_dim = z_dim
+        self.num_frequency_for_position = getattr(config, "num_frequency_for_position", 10) \
+            if not isinstance(config, dict) else config.get("num_frequency_for_position", 10)
+        self.num_frequency_for_other = getattr(config, "num_frequency_for_other", 4) \
+            if not isinstance(config, dict) else config.get("num_frequency_for_other", 4)
+        self.view_dependent = False
+        self.num_bone = num_bone - 1 if self.origin_location in ["center", "center_fixed"] else num_bone
+        self.num_joints = num_bone
+        self.use_bone_length = bone_length
+        assert parent is not None
+        self.parent_id = np.asarray(parent)
+        self.temporal_state = {}
+        self.buffers_tensors = {}
+        self.mlp_mode = getattr(config, "mlp_mode", "f16x3") if not isinstance(config, dict) else config.get("mlp_mode", "f16x3")
+        if config.constant_triplane or config.deformation_field:
+            self.tri_plane = nn.Parameter(torch.zeros(1, 32 * 3 + self.num_bone * 3, 256, 256))
+        if config.constant_triplane:
+            self.tri_plane_gen = lambda z, *args, **kwargs: self.tri_plane.expand(z.shape[0], -1, -1, -1)
+        else:
+            self.tri_plane_gen = None      # the StyleGAN2-ADA producer is out of scope: assign a callable
+        self.mlp = StyledMLP(32, 64, 4, style_dim=self.z2_dim)
+        self._cl_cache = None              # (data_ptr, _version, shape) -> channel-last copy of a constant tri-plane
+
+    # ---- canonical pose (models/narf.py:84-120) -------------------------------------------------------------------
+    def register_canonical_pose(self, pose: np.ndarray) -> None:
+        pose = np.asarray(pose)
+        par = self.parent_id[1:]
+        coordinate = pose[:, :3, 3]
+        length = np.linalg.norm(coordinate[1:] - coordinate[par], axis=1)
+        self.register_buffer("canonical_joints", torch.tensor(pose[1:, :3, 3], dtype=torch.float32))
+        self.register_buffer("canonical_parent_joints", torch.tensor(pose[par, :3, 3], dtype=torch.float32))
+        mid = (pose[1:, :, 3:] + pose[par, :, 3:]) / 2
+        if self.origin_location == "center":
+            cpose = np.concatenate([pose[1:, :, :3], mid], axis=-1)
+        elif self.origin_location == "center_fixed":
+            cpose = np.concatenate([pose[par, :, :3], mid], axis=-1)
+        else:
+            length = np.concatenate([length, np.ones(1)])
+            cpose = np.concatenate([np.concatenate([pose[par, :, :3], mid], axis=-1), pose[15][None]])
+        self.register_buffer("canonical_bone_length", torch.tensor(length, dtype=torch.float32))
+        self.register_buffer("canonical_pose", torch.tensor(cpose, dtype=torch.float32))
+
+    def transform_pose(self, pose_to_camera, bone_length):
+        return transform_pose(pose_to_camera, bone_length, self.origin_location, self.parent_id)
+
+    # ---- tri-plane handling ---------------------------------------------------------------------------------------
+    def compute_tri_plane_feature(self, z, bone_length, truncation_psi=1):
+        if self.tri_plane_gen is None:
+            raise NotImplementedError("the StyleGAN2-ADA tri-plane generator is out of scope (SURVEY.md §2): assign "
+                                      "model.tri_plane_gen or pass model_input['tri_plane_feature']")
+        if self.config.constant_triplane:
+            bs = bone_length.shape[0] if z is None else z.shape[0]
+            return self.tri_plane.expand(bs, -1, -1, -1)
+        return self.tri_plane_gen(z, bone_length, truncation_psi=truncation_psi)
+
+    def _tri_plane_pair(self, model_input: Dict):
+        """(tri-plane NCHW (1 or B images), channel-last feature planes) for this call.
+
+        A constant tri-plane (one image shared by the batch) is re-laid out once per parameter version."""
+        tri = model_input.get("tri_plane_feature")
+        if tri is None:
+            tri = self.compute_tri_plane_feature(model_input.get("z"), model_input["bone_length"],
+                                                 model_input.get("truncation_psi", 1))
+        self.buffers_tensors["tri_plane_feature"] = tri
+        if not self.training:
+            self.temporal_state["tri_plane_feature"] = tri
+        if tri.shape[0] > 1 and tri.stride(0) == 0:       # an expanded constant tri-plane
+            tri = tri[:1]
+        tri = tri.detach()
+        if not tri.is_contiguous():
+            tri = tri.contiguous()
+        key = (tri.data_ptr(), tri._version, tuple(tri.shape))
+        if self._cl_cache is not None and self._cl_cache[0] == key and tri.shape[0] == 1:
+            return tri, self._cl_cache[1]
+        cl = ops.triplane_pack(tri)
+        if tri.shape[0] == 1:
+            self._cl_cache = (key, cl)
+        return tri, cl
+
+    def _mlp_pack(self, z_rend: torch.Tensor) -> torch.Tensor:
+        _, pack = ops_prepare_mlp_only(self, z_rend)
+        return pack
+
+    # ---- the reference's entry points -------------------------------------------------------------------------------
+    def forward(self, batchsize, sampled_img_coord, pose_to_camera, inv_intrinsics, z, z_rend, bone_length,
+                render_scale=1, Nc=64, Nf=128, return_intermediate=False, truncation_psi=1,
+                camera_pose: Optional[torch.Tensor] = None, return_disparity=False, bins=None, seed=None):
+        """NARFBase.forward (libraries/NARF/base.py:26-51): raw 24-joint poses in, colour/mask(/disparity) out.
+
+        One enarf_prepare launch (part frames + modulated MLP weights) then one enarf_render_fwd launch."""
+        model_input = {"z": z, "z_rend": z_rend, "bone_length": bone_length, "truncation_psi": truncation_psi}
+        parts, pack = ops.prepare(pose_to_camera, bone_length, self.canonical_bone_length, z_rend, self.mlp.as_dict(),
+                                  self.parent_id, self.origin_location, self.coordinate_scale)
+        # part-frame count only (the kernel reads `parts`); keeps render()'s shape assertion meaningful
+        pose_parts = pose_to_camera.new_empty(pose_to_camera.shape[0], self.num_bone, 4, 4)
+        color, mask, disparity = render(self, sampled_img_coord, pose_parts, inv_intrinsics, render_scale, Nc, Nf,
+                                        return_intermediate=return_intermediate, camera_pose=camera_pose,
+                                        model_input=model_input, _parts=parts, _pack=pack, bins=bins, seed=seed)
+        if return_disparity:
+            return color, mask, disparity
+        return color, mask
+
+    def render_entire_img(self, pose_to_camera, inv_intrinsics, z, z_rend, bone_length, camera_pose=None,
+                          render_size=128, Nc=64, Nf=128, semantic_map=False, use_normalized_intrinsics=False,
+                          no_grad=True, truncation_psi=1, bbox=None):
+        """NARFBase.render_entire_img (libraries/NARF/base.py:53-63)."""
+        model_input = {"z": z, "z_rend": z_rend, "bone_length": bone_length, "truncation_psi": truncation_psi}
+        pose_parts, model_input["bone_length"] = self.transform_pose(pose_to_camera, bone_length)
+        model_input["tri_plane_feature"] = self.compute_tri_plane_feature(z, bone_length)
+        return render_entire_img(self, pose_parts, inv_intrinsics, camera_pose, render_size, Nc, Nf, semantic_map,
+                                 use_normalized_intrinsics, no_grad, model_input, bbox=bbox)
+
+    def calc_density_and_color_from_camera_coord_v2(self, position: torch.Tensor, pose_to_camera: torch.Tensor,
+                                                    ray_direction: Optional[torch.Tensor], model_input: Dict):
+        """models/narf.py:176-211: position (B,3,n) camera coords, pose_to_camera (B,P,4,4) part frames whose
+        translation is already x coordinate_scale (as render / create_mesh pass it) -> density (B,1,n), colour (B,3,n)."""
+        tri, feat_cl = self._tri_plane_pair(model_input)
+        B, P = pose_to_camera.shape[:2]
+        parts = torch.zeros(B, P, 16, dtype=torch.float32, device=position.device)
+        parts[:, :, :9] = pose_to_camera[:, :, :3, :3].reshape(B, P, 9)
+        parts[:, :, 9:12] = pose_to_camera[:, :, :3, 3]
+        parts[:, :, 12] = (self.canonical_bone_length[:, None] / model_input["bone_length"] / self.coordinate_scale)[:, :, 0]
+        pack = self._mlp_pack(model_input["z_rend"])
+        den, col, vb = ops.query_fwd(position, parts, self.canonical_pose, tri, feat_cl, pack, mlp_mode=self.mlp_mode,
+                                     multiply_density_with_weight=bool(self.config.multiply_density_with_triplane_wieght),
+                                     need_valid=True)
+        if not self.training:
+            self.temporal_state["valid_bits"] = vb
+        return den, col
+
+
+def ops_prepare_mlp_only(model: TriPlaneNARF, z_rend: torch.Tensor):
+    """enarf_prepare with parts == NULL: only the per-image modulated MLP pack."""
+    import ctypes as C
+    from .. import _lib
+    lib = _lib.load()
+    z = z_rend.float().contiguous()
+    B = z.shape[0]
+    a = _lib.PrepareArgs()
+    a.B, a.num_joints, a.origin_location, a.style_dim = B, model.num_joints, _lib.ORIGIN[model.origin_location], z.shape[1]
+    a.coordinate_scale = float(model.coordinate_scale)
+    for j in range(model.num_joints):
+        a.parents[j] = int(model.parent_id[j])
+    a.z_rend = z.data_ptr()
+    keep = []
+    sd = model.mlp.as_dict()
+    for i in range(3):
+        ts = [sd[f"layers.{i}.conv.weight"], sd[f"layers.{i}.conv.modulation.weight"],
+              sd[f"layers.{i}.conv.modulation.bias"], sd[f"layers.{i}.bias"]]
+        ts = [t.detach().float().contiguous() for t in ts]
+        keep += ts
+        a.conv_weight[i], a.mod_weight[i], a.mod_bias[i], a.bias[i] = [t.data_ptr() for t in ts]
+    pack = torch.empty(B, ops.mlp_pack_bytes(), dtype=torch.uint8, device=z.device)
+    a.parts, a.mlp_pack = None, pack.data_ptr()
+    _lib.check(lib.enarf_prepare(C.byref(a), torch.cuda.current_stream(z.device).cuda_stream), "enarf_prepare")
+    return None, pack

@@ -1,0 +1,157 @@
+"""CPU-only checks (-m "not gpu"): the C-ABI library loads and exports every symbol include/enarf_hip.h declares,
+argument validation works without touching a device, and the Python mirror keeps the reference's names."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    src = open(os.path.join(ROOT, "include", "enarf_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = re.findall(r"\b(enarf_[a-z0-9_]+)\s*\(", src)
+    return sorted(set(names))
+
+
+def test_header_symbols_all_exported_and_bound():
+    from enarf_gan_amd import _lib
+    lib = _lib.load()
+    declared = _declared_functions()
+    assert len(declared) >= 11
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in enarf_hip.h but not exported by libenarf_hip.so"
+        assert name in _lib.SIGNATURES, f"{name} has no ctypes signature in _lib.py"
+    assert set(_lib.SIGNATURES) == set(declared)
+    assert lib.enarf_abi_version() == 1
+    assert lib.enarf_mlp_pack_bytes() % 16 == 0
+
+
+def test_struct_layouts_match_the_header():
+    """Compile a tiny C program against the header and compare sizeof / offsetof with the ctypes mirrors."""
+    import subprocess
+    import tempfile
+    from enarf_gan_amd import _lib
+    fields = {"enarf_render_args": ("RenderArgs", ["B", "render_scale", "image_coord", "feat_batch_stride", "seed",
+                                                    "fine_depth", "dbg_bins", "counters"]),
+              "enarf_query_args": ("QueryArgs", ["N", "P", "points", "mask_batch_stride", "dbg_weight"]),
+              "enarf_prepare_args": ("PrepareArgs", ["coordinate_scale", "parents", "pose_to_camera", "bias", "mlp_pack"])}
+    prog = ['#include "enarf_hip.h"', "#include <stdio.h>", "#include <stddef.h>", "int main(void){"]
+    for cs, (_, fl) in fields.items():
+        prog.append(f'printf("%zu\\n", sizeof({cs}));')
+        for f in fl:
+            prog.append(f'printf("%zu\\n", offsetof({cs}, {f}));')
+    prog.append("return 0;}")
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write("\n".join(prog))
+        subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")],
+                       check=True)
+        out = subprocess.run([os.path.join(d, "t")], capture_output=True, text=True, check=True).stdout.split()
+    vals = iter(int(x) for x in out)
+    for cs, (py, fl) in fields.items():
+        st = getattr(_lib, py)
+        assert C.sizeof(st) == next(vals), cs
+        for f in fl:
+            assert getattr(st, f).offset == next(vals), f"{cs}.{f}"
+
+
+def test_argument_validation_needs_no_device():
+    from enarf_gan_amd import _lib
+    lib = _lib.load()
+    assert lib.enarf_render_fwd(None, None) == -1 and b"null" in lib.enarf_last_error()
+    a = _lib.RenderArgs()
+    a.B, a.P, a.H, a.W = 1, 40, 256, 256
+    assert lib.enarf_render_fwd(C.byref(a), None) == -1 and b"max 32 parts" in lib.enarf_last_error()
+    q = _lib.QueryArgs()
+    assert lib.enarf_query_fwd(C.byref(q), None) == -1
+    p = _lib.PrepareArgs()
+    p.B, p.num_joints, p.style_dim, p.origin_location = 1, 24, 20, 7
+    assert lib.enarf_prepare(C.byref(p), None) == -1 and b"origin_location" in lib.enarf_last_error()
+    assert lib.enarf_triplane_sample_fwd(None, None, None, 1, 1, 1, 1, 1, 0, 0, 0, None, None) == -1
+    assert lib.enarf_triplane_sample_workspace_bytes(2, 32, 256, 256) == 2 * 3 * 32 * 256 * 256 * 4
+    assert lib.enarf_triplane_sample_workspace_bytes(2, 5, 256, 256) == 0
+
+
+def test_no_cpu_fallback():
+    from enarf_gan_amd import _lib, ops
+    with pytest.raises(_lib.EnarfHipError):
+        ops.triplane_sample_fwd(torch.zeros(1, 3, 4, 4), torch.zeros(1, 2, 1, 3))
+    with pytest.raises(_lib.EnarfHipError):
+        ops.triplane_pack(torch.zeros(1, 165, 256, 256))
+
+
+class Cfg(dict):
+    __getattr__ = dict.__getitem__
+
+
+def _nerf_cfg(**kw):
+    c = Cfg(hidden_size=32, Nc=48, Nf=64, origin_location="center_fixed", coordinate_scale=3, render_bs=16384,
+            no_ray_direction=True, multiply_density_with_triplane_wieght=False, clamp_mask=False, constant_triplane=True,
+            constant_trimask=False, constant_trimask_lr_mul=1, deformation_field=False, selector_mlp=False,
+            no_selector=False, time_conditional=True, pose_conditional=False)
+    c.update(kw)
+    return c
+
+
+def test_model_mirror_keeps_reference_names_and_state_dict_keys():
+    from enarf_gan_amd import synth
+    from enarf_gan_amd.cuda_extension.triplane_sampler import (GRID_SAMPLE_INTERPOLATION_MODES,
+                                                               GRID_SAMPLE_PADDING_MODES, TriplaneSamplerFunction,
+                                                               triplane_sampler, triplane_sampler_cuda)
+    from enarf_gan_amd.models.generator import DSONARFGenerator, TriNARFGenerator
+    assert GRID_SAMPLE_INTERPOLATION_MODES == {"bilinear": 0, "nearest": 1}
+    assert GRID_SAMPLE_PADDING_MODES == {"zeros": 0, "border": 1, "reflection": 2}
+    assert callable(triplane_sampler) and hasattr(triplane_sampler_cuda, "triplane_sampler_forward")
+    assert issubclass(TriplaneSamplerFunction, torch.autograd.Function)
+    g = DSONARFGenerator(Cfg(use_triplane=True, ray_batchsize=4096, nerf_params=_nerf_cfg()), 128, 24,
+                         synth.SMPL_PARENTS, 23)
+    g.register_canonical_pose(synth.canonical_pose())
+    keys = set(g.state_dict().keys())
+    want = {"nerf.tri_plane", "nerf.canonical_pose", "nerf.canonical_bone_length", "nerf.canonical_joints",
+            "nerf.canonical_parent_joints"}
+    for i in range(3):
+        for leaf in ("bias", "conv.weight", "conv.modulation.weight", "conv.modulation.bias", "noise.weight"):
+            want.add(f"nerf.mlp.layers.{i}.{leaf}")
+    assert keys == want
+    assert g.nerf.tri_plane.shape == (1, 165, 256, 256) and g.nerf.num_bone == 23
+    assert g.nerf.mlp.layers[0].conv.modulation.weight.shape == (32, 20)       # z = PE(frame_time, 10)
+    # a reference-shaped snapshot loads strictly
+    sd = {f"nerf.mlp.{k}": v for k, v in synth.make_mlp_params(20).items()}
+    missing, unexpected = g.load_state_dict(sd, strict=False)
+    assert not unexpected
+    z1, z2 = g.get_latents(torch.tensor([0.5]), torch.zeros(1, 24, 4, 4))
+    assert z1.shape == (1, 20)
+    gan = TriNARFGenerator(Cfg(z_dim=256, background_ratio=0.7, crop_background=True, pretrained_background=False,
+                               nerf_params=_nerf_cfg(origin_location="center+head")), 128, 24, synth.SMPL_PARENTS, 23,
+                           black_background=True)
+    assert gan.nerf.num_bone == 24 and gan.nerf.tri_plane.shape[1] == 32 * 3 + 24 * 3
+    assert gan.nerf.mlp.layers[0].conv.modulation.weight.shape == (32, 256)
+
+
+def test_ray_samplers_match_reference_formulas():
+    from enarf_gan_amd import synth
+    from enarf_gan_amd.libraries.NeRF.ray_sampler import mask_based_sampler, whole_image_grid_ray_sampler
+    grid, homo = whole_image_grid_ray_sampler(16, 16, 2, device="cpu")
+    assert torch.equal(homo, synth.pixel_centres(16, 2))
+    assert grid.shape == (2, 16, 16, 2) and float(grid.min()) == -1 + 1 / 16
+    mask = torch.zeros(1, 32, 32)
+    mask[0, 10:20, 12:18] = 1
+    idx, homo = mask_based_sampler(mask, 64)
+    assert idx.shape == (1, 64) and homo.shape == (1, 1, 3, 64)
+    assert torch.equal(homo[0, 0, 0], (idx[0] % 32).float() + 0.5)
+
+
+def test_unsupported_configs_raise():
+    from enarf_gan_amd import synth
+    from enarf_gan_amd.models.narf import TriPlaneNARF
+    with pytest.raises(NotImplementedError):
+        TriPlaneNARF(_nerf_cfg(selector_mlp=True), 20, 24, parent=synth.SMPL_PARENTS)
+    with pytest.raises(NotImplementedError):
+        TriPlaneNARF(_nerf_cfg(), 20, 24, parent=synth.SMPL_PARENTS, view_dependent=True)
+    m = TriPlaneNARF(_nerf_cfg(constant_triplane=False), 20, 24, parent=synth.SMPL_PARENTS)
+    with pytest.raises(NotImplementedError):
+        m.compute_tri_plane_feature(torch.zeros(1, 20), torch.ones(1, 23, 1))

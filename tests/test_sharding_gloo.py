@@ -1,0 +1,58 @@
+"""world_size-2 gloo test of the N > 1 path: ranks render disjoint ray ranges of one frame (here with the
+oracle, since this container has no GPU) and reassemble them; the result must equal the unsharded render.
+The forward path has no data-path collective - the all_gather is only the caller's output assembly."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, n_rays, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from _helpers import Scene
+    from enarf_gan_amd import sharding
+    sc = Scene(32, 1, "center_fixed", 20)
+    coord = sc.raw["image_coord"][..., 32 * 14:32 * 14 + n_rays].contiguous()
+    bins = torch.sort(torch.rand(1, n_rays, 16, generator=torch.Generator().manual_seed(3)), dim=-1)[0]
+    sl = sharding.rays_for_rank(n_rays, rank, world)
+    rc, rm, rd = sc.oracle_render(coord[..., sl], 12, 16, bins[:, sl], taps=False)
+    full_mask = sharding.all_gather_rays(rm, n_rays)
+    full_color = sharding.all_gather_rays(rc, n_rays)
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)       # bench.py's max-over-ranks timing reduce
+    if rank == 0:
+        rc0, rm0, _ = sc.oracle_render(coord, 12, 16, bins, taps=False)
+        ret["ok"] = bool(torch.equal(full_mask, rm0) and torch.equal(full_color, rc0) and float(t) == world)
+        ret["hit"] = float((rm0 > 0).float().mean())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_ray_sharding_matches_unsharded():
+    mgr = mp.get_context("spawn").Manager()
+    ret = mgr.dict()
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, 45, ret), nprocs=2, join=True)      # 45 rays: ragged split 23 + 22
+    assert ret["ok"] and ret["hit"] > 0.1
+
+
+def test_split_range_properties():
+    from enarf_gan_amd import sharding
+    for total in (0, 1, 7, 16384, 16385):
+        for world in (1, 2, 3, 8):
+            spans = [sharding.split_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+    with pytest.raises(ValueError):
+        sharding.split_range(4, 2, 2)
+    assert list(sharding.frames_for_rank(10, 1, 4)) == [3, 4, 5]
