@@ -59,7 +59,7 @@ class RenderArgs(C.Structure):
         ("color", _f32p), ("mask", _f32p), ("disparity", _f32p), ("fine_weights", _f32p), ("fine_depth", _f32p),
         ("dbg_depth_min", _f32p), ("dbg_depth_max", _f32p), ("dbg_ray_valid", _f32p),
         ("dbg_coarse_density", _f32p), ("dbg_fine_density", _f32p), ("dbg_fine_color", _f32p),
-        ("dbg_fine_valid", _f32p), ("dbg_bins", _f32p), ("counters", _f32p),
+        ("dbg_fine_valid", _f32p), ("dbg_bins", _f32p), ("counters", _f32p), ("workspace", _f32p),
     ]
 
 
@@ -77,6 +77,7 @@ SIGNATURES = {
     "enarf_prepare": (C.c_int, [C.POINTER(PrepareArgs), C.c_void_p]),
     "enarf_mlp_unpack": (C.c_int, [C.c_void_p, _f32p, C.c_void_p]),
     "enarf_query_fwd": (C.c_int, [C.POINTER(QueryArgs), C.c_void_p]),
+    "enarf_render_workspace_bytes": (C.c_size_t, []),
     "enarf_render_fwd": (C.c_int, [C.POINTER(RenderArgs), C.c_void_p]),
 }
 

@@ -10,6 +10,10 @@
 #pragma once
 #include "enarf_device.h"
 
+#ifndef ENARF_PLANE_SERIAL
+#define ENARF_PLANE_SERIAL 1
+#endif
+
 namespace enarf {
 
 struct QueryCtx {
@@ -232,86 +236,186 @@ __device__ __forceinline__ f32x4 mlp_tile(const QueryCtx &S, const float x[8], i
     return mlp_tile_bf16<1>(S.bias, S.mlp_h, x, lane);
 }
 
-// ---- the query -------------------------------------------------------------------------------------------
-// All 64 lanes must call this together (wave-uniform control flow). `cand` is a wave-uniform bit set
-// of parts that can contain any of the wave's points; `active` marks lanes that carry a point.
-// Outputs per lane (point layout): mlp head h = (r, g, b, sigma) after the StyledConv activation
-// (valid only if bits != 0 or the lane's tile ran), bits = validity mask, wmax = max_k weight.
-template <int MODE, bool DBG>
-__device__ __forceinline__ void query_wave(const QueryCtx &S, uint32_t cand, float px, float py, float pz,
-                                           bool active, int lane, float h[4], uint32_t &bits, float &wmax,
-                                           uint64_t &tiles_run, const QueryDbg &dbg,
-                                           unsigned &n_pairs, unsigned &n_tiles) {
-    float feat[4][8];
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int c = 0; c < 8; ++c) feat[t][c] = 0.0f;
-    bits = 0;
-    wmax = 0.0f;
-    const int g = lane >> 4;
-    const float *featg = S.feat + 8 * g;
-    const size_t mplane = (size_t)S.H * S.W;
+// ---- quad (4 adjacent lanes) primitives: DPP quad_perm, no LDS -----------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ int quad_perm_i(int v) {
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, true);
+}
+template <int CTRL>
+__device__ __forceinline__ float quad_perm_f(float v) {
+    return __int_as_float(quad_perm_i<CTRL>(__float_as_int(v)));
+}
+template <int I>
+__device__ __forceinline__ float quad_bcast_f(float v) { return quad_perm_f<I * 0x55>(v); }
+template <int I>
+__device__ __forceinline__ int quad_bcast_i(int v) { return quad_perm_i<I * 0x55>(v); }
+template <int I>
+__device__ __forceinline__ Taps quad_bcast_taps(const Taps &t) {
+    Taps r;
+    r.o00 = quad_bcast_i<I>(t.o00); r.o01 = quad_bcast_i<I>(t.o01);
+    r.o10 = quad_bcast_i<I>(t.o10); r.o11 = quad_bcast_i<I>(t.o11);
+    r.w00 = quad_bcast_f<I>(t.w00); r.w01 = quad_bcast_f<I>(t.w01);
+    r.w10 = quad_bcast_f<I>(t.w10); r.w11 = quad_bcast_f<I>(t.w11);
+    return r;
+}
 
-    uint32_t m = __builtin_amdgcn_readfirstlane(cand);
-    while (m) {
-        const int k = __builtin_ctz(m);
-        m &= m - 1;
-        const float *F = S.parts + k * kPartStride;
-        const float *C = S.canon + k * 12;
-        float lx, ly, lz, cx, cy, cz;
+// part frames / canonical frames in LDS: strides chosen so that 16 different parts read in one wave
+// instruction spread over the banks (16-float stride would put parts k and k+2 on the same banks)
+constexpr int kLdsPartStride = 20;   // 16 used
+constexpr int kLdsCanonStride = 12;
+
+__device__ __forceinline__ void load_frames(const QueryCtx &S, int k, float F[13], float Cn[12]) {
+    const f32x4 *pf = reinterpret_cast<const f32x4 *>(S.parts + k * kLdsPartStride);
+    const f32x4 *pc = reinterpret_cast<const f32x4 *>(S.canon + k * kLdsCanonStride);
+    const f32x4 f0 = pf[0], f1 = pf[1], f2 = pf[2], f3 = pf[3];
+    const f32x4 c0 = pc[0], c1 = pc[1], c2 = pc[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { F[i] = f0[i]; F[4 + i] = f1[i]; F[8 + i] = f2[i]; }
+    F[12] = f3[0];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { Cn[i] = c0[i]; Cn[4 + i] = c1[i]; Cn[8 + i] = c2[i]; }
+}
+
+// ---- the query on one 16-point tile ---------------------------------------------------------------------------
+// Lane layout ("gather layout"): lane = 4 * j + g, j = point of the tile (0..15), g = 32-byte chunk of a
+// texel (channels 8g..8g+7). The 4 lanes of a point are adjacent, so a quad reads one contiguous 128-B line
+// and exchanges data with DPP quad_perm.
+//   pass A   the quad splits the candidate parts 4 ways: bone transform + cube validity -> bit mask per point
+//   rounds   round r handles the r-th valid part of every point (ascending k, the reference's summation
+//            order): part probability (lane g samples mask plane g) and the 12 feature texels of the pair in
+//            ONE memory round trip; feat[8] accumulates in registers
+//   MLP      8 cross-lane moves re-lay feat into the MFMA B-operand layout (lane = 16 g + j), then the tile MLP
+// All 64 lanes call this together. cand_list (LDS, wave-private or shared) holds `ncand` part ids.
+// Outputs: o = MLP head of point (lane & 15) in lanes < 16 (valid if ran); bits / wmax per point in gather layout.
+template <int MODE, bool DBG>
+__device__ __forceinline__ void query_tile(const QueryCtx &S, const int *cand_list, int ncand, float px, float py,
+                                           float pz, bool active, int lane, f32x4 &o, bool &ran, uint32_t &bits,
+                                           float &wmax, const QueryDbg &dbg, unsigned &n_pairs, unsigned &n_tiles) {
+    const int g = lane & 3;
+    uint32_t mine = 0;
+    for (int i0 = 0; i0 < ncand; i0 += 4) {
+        const int idx = i0 + g;
+        const bool has = idx < ncand;
+        const int k = cand_list[has ? idx : 0];
+        float F[13], Cn[12], lx, ly, lz, cx, cy, cz;
+        load_frames(S, k, F, Cn);
         exact_local(F, px, py, pz, lx, ly, lz);
-        exact_canonical(C, F[12], lx, ly, lz, cx, cy, cz);
-        const bool v = active && in_unit_cube_incl(lx, ly, lz) && in_unit_cube_strict(cx, cy, cz);
-        if (DBG) {
-            if (dbg.canonical && active) {
+        exact_canonical(Cn, F[12], lx, ly, lz, cx, cy, cz);
+        const bool v = active && has && in_unit_cube_incl(lx, ly, lz) && in_unit_cube_strict(cx, cy, cz);
+        if (v) mine |= (1u << k);
+        if (DBG && active && has) {
+            if (dbg.canonical) {
                 dbg.canonical[((size_t)k * 3 + 0) * dbg.N + dbg.i] = cx;
                 dbg.canonical[((size_t)k * 3 + 1) * dbg.N + dbg.i] = cy;
                 dbg.canonical[((size_t)k * 3 + 2) * dbg.N + dbg.i] = cz;
             }
-            if (dbg.weight && active && !v) dbg.weight[(size_t)k * dbg.N + dbg.i] = 0.125f;   // sampling.py: sigmoid(0)^3
-        }
-        const uint64_t bal = __ballot(v);
-        if (bal == 0) continue;
-        float w = 0.0f;
-        if (v && !(S.ablate & 2)) {   // part probability: product over planes of sigmoid(bilinear)  (sampling.py:43-48, :62)
-            const float *mp = S.mask + (size_t)(3 * k) * mplane;
-            const float s0 = sigmoidf_(sample_scalar_plane(mp, cx, cy, S.H, S.W));
-            const float s1 = sigmoidf_(sample_scalar_plane(mp + mplane, cy, cz, S.H, S.W));
-            const float s2 = sigmoidf_(sample_scalar_plane(mp + 2 * mplane, cz, cx, S.H, S.W));
-            w = (s0 * s1) * s2;
-            bits |= (1u << k);
-            wmax = fmaxf(wmax, w);
-            if (DBG && dbg.weight) dbg.weight[(size_t)k * dbg.N + dbg.i] = w;
-        }
-        n_pairs += (unsigned)__popcll(bal);
-        // tile layout: the 4 lanes of point (16t + j) fetch its 12 texels, 32 B each
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            if (((bal >> (16 * t)) & 0xFFFFull) == 0) continue;
-            const int src = 16 * t + (lane & 15);
-            const float qx = __shfl(cx, src), qy = __shfl(cy, src), qz = __shfl(cz, src);
-            const float qw = __shfl(w, src);
-            if (((bal >> src) & 1ull) && !(S.ablate & 1)) gather_pair(featg, S.H, S.W, qx, qy, qz, qw, feat[t]);
+            if (dbg.weight && !v) dbg.weight[(size_t)k * dbg.N + dbg.i] = 0.125f;   // sigmoid(0)^3 (sampling.py)
         }
     }
+    uint32_t b = mine | (uint32_t)quad_perm_i<0xB1>((int)mine);   // [1,0,3,2]
+    b |= (uint32_t)quad_perm_i<0x4E>((int)b);                     // [2,3,0,1]
+    bits = b;
 
-    // MLP on the tiles that hold at least one valid point
-    const uint64_t anyv = __ballot(bits != 0);
-    tiles_run = 0;
+    float feat[8];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) h[r] = 0.0f;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        if (((anyv >> (16 * t)) & 0xFFFFull) == 0 || (S.ablate & 4)) continue;
-        tiles_run |= (0xFFFFull << (16 * t));
-        n_tiles += 1;
-        const f32x4 o = mlp_tile<MODE>(S, feat[t], lane);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float val = __shfl(o[r], lane & 15);      // from the g == 0 lane of point j
-            if ((lane >> 4) == t) h[r] = val;
+    for (int c = 0; c < 8; ++c) feat[c] = 0.0f;
+    wmax = 0.0f;
+    const float *featg = S.feat + 8 * g;
+    const size_t mplane = (size_t)S.H * S.W;
+    const size_t fplane = mplane * kFeat;
+    uint32_t rem = b;
+    while (true) {
+        const uint64_t bal = __ballot(rem != 0);
+        if (bal == 0) break;
+        const bool act = rem != 0;
+        const int k = act ? __builtin_ctz(rem) : 0;
+        rem &= rem - 1;
+        float F[13], Cn[12], lx, ly, lz, cx, cy, cz;
+        load_frames(S, k, F, Cn);
+        exact_local(F, px, py, pz, lx, ly, lz);
+        exact_canonical(Cn, F[12], lx, ly, lz, cx, cy, cz);
+        // lane g owns plane g: xy, yz, zx (lane 3 repeats plane 0 and is ignored)
+        const float qx = (g == 1) ? cy : (g == 2) ? cz : cx;
+        const float qy = (g == 1) ? cz : (g == 2) ? cx : cy;
+        const Taps t = make_taps(qx, qy, S.H, S.W);
+        float sg = 1.0f;
+        if (act && g < 3 && !(S.ablate & 2)) {   // part probability plane g (sampling.py:43-48, :62)
+            const float *mp = S.mask + (size_t)(3 * k + g) * mplane;
+            float acc = mp[t.o00] * t.w00;
+            acc += mp[t.o01] * t.w01;
+            acc += mp[t.o10] * t.w10;
+            acc += mp[t.o11] * t.w11;
+            sg = sigmoidf_(acc);
         }
+        const float w = (quad_bcast_f<0>(sg) * quad_bcast_f<1>(sg)) * quad_bcast_f<2>(sg);
+#if ENARF_PLANE_SERIAL
+        // one plane's 8 loads in flight at a time: fewer VGPRs per wave, more waves per SIMD
+        float acc[8];
+        {
+            const Taps t0 = quad_bcast_taps<0>(t);
+            if (act && !(S.ablate & 1)) tap4(featg, t0, acc);
+            else {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) acc[c] = 0.0f;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const Taps t1 = quad_bcast_taps<1>(t);
+            float s1[8];
+            if (act && !(S.ablate & 1)) {
+                tap4(featg + fplane, t1, s1);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) acc[c] += s1[c];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const Taps t2 = quad_bcast_taps<2>(t);
+            float s2[8];
+            if (act && !(S.ablate & 1)) {
+                tap4(featg + 2 * fplane, t2, s2);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) acc[c] += s2[c];
+            }
+        }
+        if (act) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) feat[c] += acc[c] * w;
+            wmax = fmaxf(wmax, w);
+            if (DBG && dbg.weight && g == 0) dbg.weight[(size_t)k * dbg.N + dbg.i] = w;
+        }
+#else
+        const Taps t0 = quad_bcast_taps<0>(t), t1 = quad_bcast_taps<1>(t), t2 = quad_bcast_taps<2>(t);
+        float s0[8], s1[8], s2[8];
+        if (act && !(S.ablate & 1)) {
+            tap4(featg, t0, s0);
+            tap4(featg + fplane, t1, s1);
+            tap4(featg + 2 * fplane, t2, s2);
+        } else {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) s0[c] = s1[c] = s2[c] = 0.0f;
+        }
+        if (act) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) feat[c] += ((s0[c] + s1[c]) + s2[c]) * w;
+            wmax = fmaxf(wmax, w);
+            if (DBG && dbg.weight && g == 0) dbg.weight[(size_t)k * dbg.N + dbg.i] = w;
+        }
+#endif
+        n_pairs += (unsigned)(__popcll(bal) >> 2);
+    }
+
+    ran = (__ballot(b != 0) != 0) && !(S.ablate & 4);
+    if (ran) {
+        n_tiles += 1;
+        float x[8];
+        const int src = ((lane & 15) << 2) | (lane >> 4);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) x[c] = __shfl(feat[c], src);
+        o = mlp_tile<MODE>(S, x, lane);
+    } else {
+        o = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     }
 }
 

@@ -5,7 +5,7 @@
 #include <cstdlib>
 
 #ifndef ENARF_RENDER_WAVES_PER_SIMD
-#define ENARF_RENDER_WAVES_PER_SIMD 2
+#define ENARF_RENDER_WAVES_PER_SIMD 3
 #endif
 
 namespace enarf {
@@ -146,14 +146,15 @@ __global__ void mlp_unpack_kernel(const float *__restrict__ pf, float *__restric
 // =================================================================================================
 // LDS staging shared by the query and render kernels
 // =================================================================================================
-// dynamic LDS layout (floats): [mlp section][bias 144][parts P*16][canon P*12][scratch 160]
+// dynamic LDS layout (floats): [mlp section][bias 144][parts P*20][canon P*12][scratch kScratchFloats]
+constexpr int kScratchFloats = 1024;
 template <int MODE>
 __host__ __device__ constexpr int lds_mlp_floats() {
     return (MODE == ENARF_MLP_F32) ? PK_B1 : PKH_SHORTS / 2;
 }
 template <int MODE>
 __host__ __device__ inline int lds_total_floats(int P) {
-    return lds_mlp_floats<MODE>() + 144 + P * kPartStride + P * 12 + 160;
+    return lds_mlp_floats<MODE>() + 144 + P * kLdsPartStride + P * kLdsCanonStride + kScratchFloats;
 }
 
 template <int MODE>
@@ -163,8 +164,8 @@ __device__ __forceinline__ void stage_common(float *lds, QueryCtx &S, float *&sc
     float *l_mlp = lds;
     float *l_bias = l_mlp + lds_mlp_floats<MODE>();
     float *l_parts = l_bias + 144;
-    float *l_canon = l_parts + P * kPartStride;
-    scratch = l_canon + P * 12;
+    float *l_canon = l_parts + P * kLdsPartStride;
+    scratch = l_canon + P * kLdsCanonStride;
     const float *pf = reinterpret_cast<const float *>(pack_b);
     const f32x4 *src4 = (MODE == ENARF_MLP_F32) ? reinterpret_cast<const f32x4 *>(pf)
                         : (MODE == ENARF_MLP_F16X3) ? reinterpret_cast<const f32x4 *>(pf + PK_F32_FLOATS + PKH_SHORTS / 2)
@@ -172,7 +173,8 @@ __device__ __forceinline__ void stage_common(float *lds, QueryCtx &S, float *&sc
     f32x4 *dst4 = reinterpret_cast<f32x4 *>(l_mlp);
     for (int i = tid; i < lds_mlp_floats<MODE>() / 4; i += nthreads) dst4[i] = src4[i];
     for (int i = tid; i < 144; i += nthreads) l_bias[i] = pf[PK_B1 + i];
-    for (int i = tid; i < P * kPartStride; i += nthreads) l_parts[i] = parts_b[i];
+    for (int i = tid; i < P * kPartStride; i += nthreads)
+        l_parts[(i / kPartStride) * kLdsPartStride + (i % kPartStride)] = parts_b[i];
     for (int i = tid; i < P * 12; i += nthreads) {   // (P,4,4) -> Rc row-major 9 + tc 3
         const int k = i / 12, e = i % 12;
         l_canon[i] = (e < 9) ? canon_pose[k * 16 + (e / 3) * 4 + (e % 3)] : canon_pose[k * 16 + (e - 9) * 4 + 3];
@@ -198,7 +200,7 @@ __device__ __forceinline__ float density_head(float sigma_act, uint32_t bits, fl
 }
 
 // =================================================================================================
-// enarf_query_fwd: a wave takes 64 consecutive points of one image
+// enarf_query_fwd: a wave takes 16 points at a time (one MFMA tile), 4 adjacent lanes per point
 // =================================================================================================
 template <int MODE, bool DBG>
 __global__ __launch_bounds__(256) void query_kernel(const enarf_query_args a, int wgs_per_image, int pts_per_wg) {
@@ -214,55 +216,59 @@ __global__ __launch_bounds__(256) void query_kernel(const enarf_query_args a, in
     S.mask = a.mask_planes + (size_t)b * a.mask_batch_stride;
     S.H = a.H; S.W = a.W; S.P = a.P; S.mult_w = a.multiply_density_with_weight;
     S.ablate = 0;
+    int *l_cand = reinterpret_cast<int *>(scratch + 8);
+    if (tid < a.P) l_cand[tid] = tid;                 // every part is a candidate for a free point cloud
     __syncthreads();
 
     // colour of a point with no valid part: the reference still runs the MLP on a zero feature
     // (narf.py:255-268), a per-image constant; wave 0 computes it once per workgroup.
     if (wave == 0) {
         float zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        const f32x4 o = mlp_tile<MODE>(S, zero, lane);
-        if (lane == 0) { scratch[0] = o[0]; scratch[1] = o[1]; scratch[2] = o[2]; }
+        const f32x4 z = mlp_tile<MODE>(S, zero, lane);
+        if (lane == 0) { scratch[0] = z[0]; scratch[1] = z[1]; scratch[2] = z[2]; }
     }
     __syncthreads();
     const float c0r = tanhf(scratch[0]), c0g = tanhf(scratch[1]), c0b = tanhf(scratch[2]);
 
     const long long N = a.N;
-    const uint32_t all_parts = (a.P >= 32) ? 0xFFFFFFFFu : ((1u << a.P) - 1u);
     const long long base = (long long)chunk * pts_per_wg;
-    for (long long off = (long long)wave * 64; off < pts_per_wg; off += 256) {
-        const long long i = base + off + lane;
+    const float *pp = a.points + (size_t)b * 3 * N;
+    for (long long off = (long long)wave * 16; off < pts_per_wg; off += 64) {
         if (base + off >= N) break;   // uniform
+        const long long i = base + off + (lane >> 2);
         const bool active = i < N;
         const long long ic = active ? i : N - 1;
-        const float *pp = a.points + (size_t)b * 3 * N;
         const float px = pp[ic], py = pp[N + ic], pz = pp[2 * N + ic];
         QueryDbg dbg{nullptr, nullptr, N, ic};
         if (DBG) {
             dbg.canonical = a.dbg_canonical ? a.dbg_canonical + (size_t)b * a.P * 3 * N : nullptr;
             dbg.weight = a.dbg_weight ? a.dbg_weight + (size_t)b * a.P * N : nullptr;
         }
-        float h[4];
+        f32x4 o;
+        bool ran;
         uint32_t bits;
         float wmax;
-        uint64_t tiles;
         unsigned np = 0, nt = 0;
-        query_wave<MODE, DBG>(S, all_parts, px, py, pz, active, lane, h, bits, wmax, tiles, dbg, np, nt);
-        if (active) {
-            const bool ran = (tiles >> lane) & 1ull;
-            a.density[(size_t)b * N + i] = density_head(h[3], bits, wmax, S.mult_w, S.P);
+        query_tile<MODE, DBG>(S, l_cand, a.P, px, py, pz, active, lane, o, ran, bits, wmax, dbg, np, nt);
+        // MFMA-layout lanes 0..15 hold the head of point (lane); fetch that point's bits / wmax from its quad
+        const uint32_t pbits = (uint32_t)__shfl((int)bits, (lane & 15) << 2);
+        const float pwmax = __shfl(wmax, (lane & 15) << 2);
+        const long long io = base + off + lane;
+        if (lane < 16 && io < N) {
+            a.density[(size_t)b * N + io] = density_head(o[3], pbits, pwmax, S.mult_w, S.P);
             if (a.color) {
                 float *c = a.color + (size_t)b * 3 * N;
-                c[i] = ran ? tanhf(h[0]) : c0r;
-                c[N + i] = ran ? tanhf(h[1]) : c0g;
-                c[2 * N + i] = ran ? tanhf(h[2]) : c0b;
+                c[io] = ran ? tanhf(o[0]) : c0r;
+                c[N + io] = ran ? tanhf(o[1]) : c0g;
+                c[2 * N + io] = ran ? tanhf(o[2]) : c0b;
             }
-            if (a.valid_bits) a.valid_bits[(size_t)b * N + i] = bits;
+            if (a.valid_bits) a.valid_bits[(size_t)b * N + io] = pbits;
         }
     }
 }
 
 // =================================================================================================
-// enarf_render_fwd: one wavefront per ray; lanes = samples along the ray
+// enarf_render_fwd: one workgroup (4 waves) per ray; each wave owns a quarter of the samples of a pass
 // =================================================================================================
 // bitonic sort of one value per lane, ascending across the wave
 __device__ __forceinline__ float wave_sort64(float v, int lane) {
@@ -306,28 +312,56 @@ __device__ __forceinline__ bool ray_hits_part(const float *F, float dx, float dy
     return t0 <= t1;
 }
 
+// wave-private compaction of a part bit set into an LDS list; returns the count
+__device__ __forceinline__ int build_cand_list(int *list, uint32_t set, int lane) {
+    if (lane < 32 && ((set >> lane) & 1u)) list[__popc(set & ((1u << lane) - 1u))] = lane;
+    return __popc(set);
+}
+
+// scratch layout (floats) of the render kernel
+constexpr int SC_DTAB = 0;       // 32 range-test depths
+constexpr int SC_BTAB = 32;      // Nc + 1 bin edges (<= 65)
+constexpr int SC_RED = 100;      // 8 partial min/max + near/far
+constexpr int SC_CAND = 112;     // 4 waves x 32 ints
+constexpr int SC_CH = 240;       // coarse: sigma head [64]
+constexpr int SC_CBITS = 304;    // coarse: bits [64]
+constexpr int SC_CWMAX = 368;    // coarse: wmax [64]
+constexpr int SC_FH = 432;       // fine: head [4][64]
+constexpr int SC_FBITS = 688;    // fine: bits [64]
+constexpr int SC_FWMAX = 752;    // fine: wmax [64]
+constexpr int SC_QUEUE = 816;    // 2 ray ids (current / prefetched)
+static_assert(SC_QUEUE + 2 <= kScratchFloats, "scratch overflow");
+
 template <int MODE>
-__global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kernel(const enarf_render_args a, int wgs_per_image, int rays_per_wg,
-                                                                                  int xcd_chunked, int ablate, int ray_strided) {
+__global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kernel(const enarf_render_args a, int ablate) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // Tile mapping. With >= 8 images each XCD takes whole images (their tri-planes stay in that XCD's L2);
-    // with fewer, tiles are dealt round-robin so the dense middle of a frame is spread over all 8 XCDs.
-    const int bid = xcd_chunked ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-    const int b = bid / wgs_per_image, tile = bid % wgs_per_image;
+    // Persistent workgroups pull consecutive ray ids (over all images) from one atomic queue head: perfect load
+    // balance whatever the mix of hit / miss rays, and at any moment the whole chip works on a window of a few
+    // image rows, whose tri-plane footprint stays in every XCD's L2.
     const int P = a.P, Nc = a.Nc, Nf = a.Nf, n = a.n;
+    const long long total_rays = (long long)a.B * n;
+    unsigned int *queue = reinterpret_cast<unsigned int *>(a.workspace);
 
     QueryCtx S;
-    float *scratch;
+    float *scratch = lds + (lds_total_floats<MODE>(P) - kScratchFloats);
+    int *l_q = reinterpret_cast<int *>(scratch + SC_QUEUE);
+    if (tid == 0) l_q[0] = (int)atomicAdd(queue, 1u);
+    __syncthreads();
+    long long cur = (unsigned int)l_q[0];
+    if (cur >= total_rays) return;            // uniform: more workgroups than rays
+    int b = (int)(cur / n);
     stage_common<MODE>(lds, S, scratch, reinterpret_cast<const char *>(a.mlp_pack) + (size_t)b * kPackBytes,
                        a.parts + (size_t)b * P * kPartStride, a.canonical_pose, P, tid, 256);
     S.feat = a.feat_cl + (size_t)b * a.feat_batch_stride;
     S.mask = a.mask_planes + (size_t)b * a.mask_batch_stride;
     S.H = a.H; S.W = a.W; S.P = P; S.mult_w = a.multiply_density_with_weight;
     S.ablate = ablate;
-    float *l_dtab = scratch;          // 32 range-test depths
-    float *l_btab = scratch + 32;     // Nc + 1 bin edges (<= 65)
-    float *l_red = scratch + 100;     // 8 partials + near/far
+    float *l_dtab = scratch + SC_DTAB, *l_btab = scratch + SC_BTAB, *l_red = scratch + SC_RED;
+    int *l_cand = reinterpret_cast<int *>(scratch + SC_CAND) + wave * 32;
+    float *l_ch = scratch + SC_CH, *l_cwmax = scratch + SC_CWMAX, *l_fh = scratch + SC_FH, *l_fwmax = scratch + SC_FWMAX;
+    uint32_t *l_cbits = reinterpret_cast<uint32_t *>(scratch + SC_CBITS);
+    uint32_t *l_fbits = reinterpret_cast<uint32_t *>(scratch + SC_FBITS);
 
     // ---- batch-global near / far planes (rendering.py:15-17): min / max of every part centre's z
     {
@@ -356,90 +390,114 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
     __syncthreads();
 
     unsigned n_pairs = 0, n_tiles = 0, n_rays = 0;
-    const float *coord = a.image_coord + (size_t)b * 3 * n;
-    const float *Ki = a.inv_intrinsics + (size_t)b * 9;
+    int qslot = 0;
     const QueryDbg nodbg{nullptr, nullptr, 0, 0};
+    const int Tc = (Nc + 3) >> 2, Tf = (Nf + 3) >> 2;     // samples per wave (<= 16)
+    const int j4 = lane >> 2;                              // this lane's sample within the wave's tile
+    const bool dbgq = (a.dbg_fine_density != nullptr);
 
-    for (int r = wave; r < rays_per_wg; r += 4) {
-        // rays are dealt to workgroups with a stride of wgs_per_image: every workgroup gets the same mix of
-        // rays that hit the body and rays that miss, so workgroup run times are even
-        const int ray = __builtin_amdgcn_readfirstlane(ray_strided ? r * wgs_per_image + tile : tile * rays_per_wg + r);
-        if (ray >= n) { if (ray_strided) break; else break; }
+    while (cur < total_rays) {
+        if (tid == 0) l_q[qslot ^ 1] = (int)atomicAdd(queue, 1u);   // prefetch the next id; read after the S0 barrier
+        const int nb = (int)(cur / n), ray = (int)(cur - (long long)nb * n);
+        if (nb != b) {   // next image: restage its MLP pack and part frames (ids are consecutive, so this is rare)
+            b = nb;
+            __syncthreads();
+            stage_common<MODE>(lds, S, scratch, reinterpret_cast<const char *>(a.mlp_pack) + (size_t)b * kPackBytes,
+                               a.parts + (size_t)b * P * kPartStride, a.canonical_pose, P, tid, 256);
+            S.feat = a.feat_cl + (size_t)b * a.feat_batch_stride;
+            S.mask = a.mask_planes + (size_t)b * a.mask_batch_stride;
+            __syncthreads();
+        }
+        const float *coord = a.image_coord + (size_t)b * 3 * n;
+        const float *Ki = a.inv_intrinsics + (size_t)b * 9;
         // ---- ray direction K^-1 [u v w]  (rendering.py:26-38)
         const float u = coord[ray], v = coord[n + ray], w = coord[2 * n + ray];
         const float dx = exact_dot3(Ki[0], u, Ki[1], v, Ki[2], w);
         const float dy = exact_dot3(Ki[3], u, Ki[4], v, Ki[5], w);
         const float dz = exact_dot3(Ki[6], u, Ki[7], v, Ki[8], w);
 
-        // ---- candidate parts over [near, far]: lane k tests part k
-        const uint32_t cand_all = (uint32_t)__ballot(lane < P &&
-                                                     ray_hits_part(S.parts + min(lane, P - 1) * kPartStride, dx, dy, dz, near_p, far_p));
-
-        // ---- depth range: 32 depths x parts cube test (rendering.py:40-70); lane = (depth, half of the parts)
+        // ---- S0: depth range (rendering.py:40-70): 32 depths x candidate parts, all 256 threads.
+        // Each wave keeps a private list of the parts the ray can touch in [near, far]; half-wave
+        // (depth = tid & 31, slot = tid >> 5) tests candidates slot, slot + 8, ...
+        const uint32_t cand_all = (uint32_t)__ballot(lane < P && ray_hits_part(S.parts + min(lane, P - 1) * kLdsPartStride,
+                                                                              dx, dy, dz, near_p, far_p));
+        const int ncand_all = build_cand_list(l_cand, cand_all, lane);
         float dmin, dmax;
         bool ray_valid;
         {
-            const int di = lane & 31, half = lane >> 5;
-            const float ds = l_dtab[di];
+            const float ds = l_dtab[tid & 31];
             const float qx = exact_mul(dx, ds), qy = exact_mul(dy, ds), qz = exact_mul(dz, ds);
             bool inside = false;
-            uint32_t m = cand_all;
-            while (m) {   // the two 32-lane halves take alternate candidate parts
-                const int k0 = __builtin_ctz(m);
-                m &= m - 1;
-                int k1 = -1;
-                if (m) { k1 = __builtin_ctz(m); m &= m - 1; }
-                const int k = half ? k1 : k0;
-                if (k >= 0) {
-                    float lx, ly, lz;
-                    exact_local(S.parts + k * kPartStride, qx, qy, qz, lx, ly, lz);
-                    inside = inside || in_unit_cube_incl(lx, ly, lz);
-                }
+            for (int i = tid >> 5; i < ncand_all; i += 8) {
+                float lx, ly, lz;
+                exact_local(S.parts + l_cand[i] * kLdsPartStride, qx, qy, qz, lx, ly, lz);
+                inside = inside || in_unit_cube_incl(lx, ly, lz);
             }
-            dmin = wave_min(inside ? ds : 1.0e3f);
-            dmax = wave_max(inside ? ds : -1.0e3f);
+            const float mn = wave_min(inside ? ds : 1.0e3f), mx = wave_max(inside ? ds : -1.0e3f);
+            if (lane == 0) { l_red[wave] = mn; l_red[4 + wave] = mx; }
+            __syncthreads();
+            dmin = fminf(fminf(l_red[0], l_red[1]), fminf(l_red[2], l_red[3]));
+            dmax = fmaxf(fmaxf(l_red[4], l_red[5]), fmaxf(l_red[6], l_red[7]));
             ray_valid = (dmin != 1.0e3f);
             dmin = ray_valid ? dmin : near_p;
             dmax = (dmax != -1.0e3f) ? dmax : far_p;
             dmin = fmaxf(dmin, near_p);
         }
-        if (a.dbg_depth_min && lane == 0) {
+        const long long next_ray = (unsigned int)l_q[qslot ^ 1];
+        qslot ^= 1;
+        if (a.dbg_depth_min && tid == 0) {
             a.dbg_depth_min[(size_t)b * n + ray] = dmin;
             a.dbg_depth_max[(size_t)b * n + ray] = dmax;
             a.dbg_ray_valid[(size_t)b * n + ray] = ray_valid ? 1 : 0;
         }
         if (a.drop_invalid_rays && !ray_valid) {   // rendering.py:107-110 / :337-350: zeros
-            if (lane < 3) a.color[((size_t)b * 3 + lane) * n + ray] = 0.0f;
-            if (lane == 3) a.mask[(size_t)b * n + ray] = 0.0f;
-            if (lane == 4) a.disparity[(size_t)b * n + ray] = 0.0f;
-            if (a.fine_weights && lane < Nf - 1) a.fine_weights[((size_t)b * n + ray) * (Nf - 1) + lane] = 0.0f;
-            if (a.fine_depth && lane < Nf) a.fine_depth[((size_t)b * n + ray) * Nf + lane] = 0.0f;
+            if (wave == 0) {
+                if (lane < 3) a.color[((size_t)b * 3 + lane) * n + ray] = 0.0f;
+                if (lane == 3) a.mask[(size_t)b * n + ray] = 0.0f;
+                if (lane == 4) a.disparity[(size_t)b * n + ray] = 0.0f;
+                if (a.fine_weights && lane < Nf - 1) a.fine_weights[((size_t)b * n + ray) * (Nf - 1) + lane] = 0.0f;
+                if (a.fine_depth && lane < Nf) a.fine_depth[((size_t)b * n + ray) * Nf + lane] = 0.0f;
+            }
+            __syncthreads();   // l_red is rewritten by the next ray
+            cur = next_ray;
             continue;
         }
-        n_rays += 1;
+        if (wave == 0) n_rays += 1;
         // candidate parts over the marched segment only
         const uint32_t cand = (uint32_t)__ballot(lane < P && ((cand_all >> lane) & 1u) &&
-                                                 ray_hits_part(S.parts + min(lane, P - 1) * kPartStride, dx, dy, dz, dmin, dmax));
+                                                 ray_hits_part(S.parts + min(lane, P - 1) * kLdsPartStride, dx, dy, dz, dmin, dmax));
+        const int ncand = build_cand_list(l_cand, cand, lane);
         const float sx = exact_mul(dmin, dx), sy = exact_mul(dmin, dy), sz = exact_mul(dmin, dz);
         const float ex = exact_mul(dmax, dx), ey = exact_mul(dmax, dy), ez = exact_mul(dmax, dz);
 
-        // ---- coarse pass: lane i < Nc is the mid-point of bin i (rendering.py:119-131)
-        float ws;   // smoothed coarse weight of this lane's bin
+        // ---- S1: coarse pass, wave w owns bins [w Tc, (w+1) Tc)  (rendering.py:119-131, :172)
         {
-            const int ci = min(lane, Nc - 1);
+            const int i = wave * Tc + j4;
+            const bool active = (j4 < Tc) && (i < Nc);
+            const int ci = min(i, Nc - 1);
             const float b0 = l_btab[ci], b1 = l_btab[ci + 1];
             const float px = exact_mid(exact_lerp(sx, ex, b1), exact_lerp(sx, ex, b0));
             const float py = exact_mid(exact_lerp(sy, ey, b1), exact_lerp(sy, ey, b0));
             const float pz = exact_mid(exact_lerp(sz, ez, b1), exact_lerp(sz, ez, b0));
-            const float delta = exact_lerp(dmin, dmax, b1) - exact_lerp(dmin, dmax, b0);
-            const bool active = lane < Nc;
-            float h[4], wmax;
+            f32x4 o;
+            bool ran;
             uint32_t bits;
-            uint64_t tiles;
-            query_wave<MODE, false>(S, cand, px, py, pz, active, lane, h, bits, wmax, tiles, nodbg, n_pairs, n_tiles);
-            const float den = active ? density_head(h[3], bits, wmax, S.mult_w, P) : 0.0f;
-            if (a.dbg_coarse_density && active) a.dbg_coarse_density[((size_t)b * n + ray) * Nc + lane] = den;
-            // weights (rendering.py:180-184) and smoothing (:187-190)
+            float wmax;
+            query_tile<MODE, false>(S, l_cand, ncand, px, py, pz, active, lane, o, ran, bits, wmax, nodbg, n_pairs, n_tiles);
+            if (lane < Tc && wave * Tc + lane < Nc) l_ch[wave * Tc + lane] = o[3];
+            if (active && (lane & 3) == 0) { l_cbits[i] = bits; l_cwmax[i] = wmax; }
+        }
+        __syncthreads();
+
+        // ---- S2 (every wave, lane = sample): weights (rendering.py:180-184), smoothing (:187-190), bins (:192-197)
+        float bin;
+        {
+            const bool active = lane < Nc;
+            const int ci = min(lane, Nc - 1);
+            const float den = active ? density_head(l_ch[ci], l_cbits[ci], l_cwmax[ci], S.mult_w, P) : 0.0f;
+            if (a.dbg_coarse_density && active && wave == 0) a.dbg_coarse_density[((size_t)b * n + ray) * Nc + lane] = den;
+            const float b0 = l_btab[ci], b1 = l_btab[ci + 1];
+            const float delta = exact_lerp(dmin, dmax, b1) - exact_lerp(dmin, dmax, b0);
             const float dd = active ? den * delta * a.render_scale : 0.0f;
             const float cs = wave_scan_incl(dd, lane);
             const float T = expf(-(cs - dd));
@@ -447,45 +505,57 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
             float wl = __shfl_up(wgt, 1), wr = __shfl_down(wgt, 1);
             if (lane == 0) wl = 0.0f;
             if (lane >= Nc - 1) wr = 0.0f;
-            ws = active ? (fmaxf(wl, wgt) + fmaxf(wgt, wr)) / 2.0f + 0.01f : 0.0f;
-        }
-
-        // ---- importance samples (rendering.py:192-200)
-        float bin;
-        if (a.bins) {
-            bin = a.bins[((size_t)b * n + ray) * Nf + min(lane, Nf - 1)];
-        } else {
-            const float cdf = wave_scan_incl(ws, lane);
-            const float total = __shfl(cdf, Nc - 1);
-            uint32_t rnd[4];
-            const uint64_t gid = (uint64_t)b * (uint64_t)n + (uint64_t)ray;
-            philox4x32((uint32_t)gid, (uint32_t)(gid >> 32), (uint32_t)lane, 0x454E4152u,
-                       (uint32_t)a.seed, (uint32_t)(a.seed >> 32), rnd);
-            const float target = u32_to_unit(rnd[0]) * total;
-            int lo = 0, hi = Nc - 1;   // smallest i with cdf[i] > target
+            const float ws = active ? (fmaxf(wl, wgt) + fmaxf(wgt, wr)) / 2.0f + 0.01f : 0.0f;
+            if (a.bins) {
+                bin = a.bins[((size_t)b * n + ray) * Nf + min(lane, Nf - 1)];
+            } else {
+                const float cdf = wave_scan_incl(ws, lane);
+                const float total = __shfl(cdf, Nc - 1);
+                uint32_t rnd[4];
+                const uint64_t gid = (uint64_t)b * (uint64_t)n + (uint64_t)ray;
+                philox4x32((uint32_t)gid, (uint32_t)(gid >> 32), (uint32_t)lane, 0x454E4152u,
+                           (uint32_t)a.seed, (uint32_t)(a.seed >> 32), rnd);
+                const float target = u32_to_unit(rnd[0]) * total;
+                int lo = 0, hi = Nc - 1;   // smallest i with cdf[i] > target
 #pragma unroll
-            for (int it = 0; it < 6; ++it) {
-                const int mid = (lo + hi) >> 1;
-                const float c = __shfl(cdf, mid);
-                if (lo < hi) { if (c > target) hi = mid; else lo = mid + 1; }
+                for (int it = 0; it < 6; ++it) {
+                    const int mid = (lo + hi) >> 1;
+                    const float c = __shfl(cdf, mid);
+                    if (lo < hi) { if (c > target) hi = mid; else lo = mid + 1; }
+                }
+                const float raw = (float)lo / (float)Nc + u32_to_unit(rnd[1]) / (float)Nc;
+                bin = wave_sort64(lane < Nf ? raw : 3.0e38f, lane);
             }
-            const float raw = (float)lo / (float)Nc + u32_to_unit(rnd[1]) / (float)Nc;
-            bin = wave_sort64(lane < Nf ? raw : 3.0e38f, lane);
+            if (a.dbg_bins && lane < Nf && wave == 0) a.dbg_bins[((size_t)b * n + ray) * Nf + lane] = bin;
         }
-        if (a.dbg_bins && lane < Nf) a.dbg_bins[((size_t)b * n + ray) * Nf + lane] = bin;
 
-        // ---- fine pass + compositing (rendering.py:283-335); the last sample only closes the last interval
+        // ---- S3: fine pass, wave w owns samples [w Tf, (w+1) Tf); the last sample only closes the last interval
         {
-            const float fdepth = exact_lerp(dmin, dmax, bin);
-            const float px = exact_lerp(sx, ex, bin), py = exact_lerp(sy, ey, bin), pz = exact_lerp(sz, ez, bin);
-            const bool dbgq = (a.dbg_fine_density != nullptr);
-            const bool active = dbgq ? (lane < Nf) : (lane < Nf - 1);
-            float h[4], wmax;
+            const int i = wave * Tf + j4;
+            const bool active = (j4 < Tf) && (i < (dbgq ? Nf : Nf - 1));
+            const float bi = __shfl(bin, min(i, Nf - 1));
+            const float px = exact_lerp(sx, ex, bi), py = exact_lerp(sy, ey, bi), pz = exact_lerp(sz, ez, bi);
+            f32x4 o;
+            bool ran;
             uint32_t bits;
-            uint64_t tiles;
-            query_wave<MODE, false>(S, cand, px, py, pz, active, lane, h, bits, wmax, tiles, nodbg, n_pairs, n_tiles);
-            const float den = active ? density_head(h[3], bits, wmax, S.mult_w, P) : 0.0f;
-            const float cr = tanhf(h[0]), cg = tanhf(h[1]), cb = tanhf(h[2]);
+            float wmax;
+            query_tile<MODE, false>(S, l_cand, ncand, px, py, pz, active, lane, o, ran, bits, wmax, nodbg, n_pairs, n_tiles);
+            if (lane < Tf && wave * Tf + lane < Nf) {
+                const int io = wave * Tf + lane;
+                l_fh[io] = o[0]; l_fh[64 + io] = o[1]; l_fh[128 + io] = o[2]; l_fh[192 + io] = o[3];
+            }
+            if ((j4 < Tf) && (i < Nf) && (lane & 3) == 0) { l_fbits[i] = active ? bits : 0u; l_fwmax[i] = wmax; }
+        }
+        __syncthreads();
+
+        // ---- S4 (wave 0, lane = sample): compositing (rendering.py:307-335)
+        if (wave == 0) {
+            const int ci = min(lane, Nf - 1);
+            const bool have = lane < (dbgq ? Nf : Nf - 1);
+            const uint32_t bits = l_fbits[ci];
+            const float den = have ? density_head(l_fh[192 + ci], bits, l_fwmax[ci], S.mult_w, P) : 0.0f;
+            const float cr = tanhf(l_fh[ci]), cg = tanhf(l_fh[64 + ci]), cb = tanhf(l_fh[128 + ci]);
+            const float fdepth = exact_lerp(dmin, dmax, bin);
             if (dbgq && lane < Nf) {
                 const size_t o = ((size_t)b * n + ray) * Nf + lane;
                 a.dbg_fine_density[o] = den;
@@ -515,6 +585,10 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
             if (a.fine_weights && seg) a.fine_weights[((size_t)b * n + ray) * (Nf - 1) + lane] = wgt;
             if (a.fine_depth && lane < Nf) a.fine_depth[((size_t)b * n + ray) * Nf + lane] = fdepth;
         }
+        // no barrier needed here: the next ray's S0 barrier comes before anything this wave reads is rewritten
+        // (coarse arrays are rewritten in S1', fine arrays in S3', l_red before the S0' barrier - and wave 0 reads
+        // l_red only right after that barrier).
+        cur = next_ray;
     }
     if (a.counters && lane == 0) {
         atomicAdd(&a.counters[0], (unsigned long long)n_pairs);
@@ -567,7 +641,7 @@ extern "C" int enarf_mlp_unpack(const void *pack, float *dense, enarf_stream_t s
 
 template <int MODE>
 static int launch_query(const enarf_query_args &a, hipStream_t st) {
-    const int pts_per_wg = 1024;
+    const int pts_per_wg = 1024;   // 16 tiles of 16 points per wave
     const long long wgs = (a.N + pts_per_wg - 1) / pts_per_wg;
     if (wgs * a.B > 0x7FFFFFFFll) return host::fail(ENARF_ERR_UNSUPPORTED, "enarf_query_fwd: too many points for one launch");
     const size_t lds = (size_t)lds_total_floats<MODE>(a.P) * 4;
@@ -604,20 +678,30 @@ extern "C" int enarf_query_fwd(const enarf_query_args *args, enarf_stream_t stre
 
 template <int MODE>
 static int launch_render(const enarf_render_args &a, hipStream_t st) {
-    // rays per workgroup: enough workgroups to fill 256 CUs several times over, few enough that the
-    // per-workgroup LDS staging (~30 KB) is amortised
+    // persistent grid: as many workgroups as stay resident (3 per CU at <= 168 VGPRs and ~37 KB LDS), never more
+    // than there are rays
+    static int num_cus = 0;
+    if (num_cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
+            return host::fail((int)hipGetLastError(), "enarf_render_fwd: cannot query the device");
+        num_cus = prop.multiProcessorCount;
+    }
     const long long total = (long long)a.B * a.n;
-    int rpw = 64;
-    while (rpw > 8 && total / rpw < 4096) rpw >>= 1;
+    const char *wp = getenv("ENARF_WGS_PER_CU");      // tuning only
+    const int per_cu = (wp && atoi(wp) > 0) ? atoi(wp) : ENARF_RENDER_WAVES_PER_SIMD;
+    long long wgs = (long long)num_cus * per_cu;
+    if (wgs > total) wgs = total;
     const size_t lds = (size_t)lds_total_floats<MODE>(a.P) * 4;
     const char *ab = getenv("ENARF_ABLATE");      // diagnosis only: 1 skip feature gathers, 2 skip mask planes, 4 skip MLP
-    const char *rp = getenv("ENARF_RAYS_PER_WG");
-    if (rp && atoi(rp) > 0) rpw = atoi(rp);
-    const int wgs = (a.n + rpw - 1) / rpw;
-    hipLaunchKernelGGL(render_kernel<MODE>, dim3((unsigned)(wgs * a.B)), dim3(256), lds, st, a, wgs, rpw,
-                       a.B >= 8 ? 1 : 0, ab ? atoi(ab) : 0, getenv("ENARF_NO_STRIDE") ? 0 : 1);
+    hipError_t e = hipMemsetAsync(a.workspace, 0, 64, st);
+    if (e != hipSuccess) return host::fail((int)e, "enarf_render_fwd: hipMemsetAsync(workspace) failed: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(render_kernel<MODE>, dim3((unsigned)wgs), dim3(256), lds, st, a, ab ? atoi(ab) : 0);
     return host::check_launch("enarf_render_fwd");
 }
+
+extern "C" size_t enarf_render_workspace_bytes(void) { return 64; }
 
 extern "C" int enarf_render_fwd(const enarf_render_args *args, enarf_stream_t stream) {
     if (!args) return host::fail(ENARF_ERR_ARG, "enarf_render_fwd: args is null");
@@ -632,7 +716,8 @@ extern "C" int enarf_render_fwd(const enarf_render_args *args, enarf_stream_t st
                                                  "(one lane per sample)", a.Nc, a.Nf);
     if (a.dbg_depth_min && (!a.dbg_depth_max || !a.dbg_ray_valid))
         return host::fail(ENARF_ERR_ARG, "enarf_render_fwd: dbg_depth_min needs dbg_depth_max and dbg_ray_valid");
-    if ((long long)((a.n + 7) / 8) * a.B > 0x7FFFFFFFll) return host::fail(ENARF_ERR_UNSUPPORTED, "enarf_render_fwd: too many rays for one launch");
+    if ((long long)a.n * a.B > 0x7FFFFFF0ll) return host::fail(ENARF_ERR_UNSUPPORTED, "enarf_render_fwd: more than 2^31 rays in one launch");
+    if (!a.workspace) return host::fail(ENARF_ERR_ARG, "enarf_render_fwd: workspace is null (enarf_render_workspace_bytes() bytes of device memory)");
     hipStream_t st = (hipStream_t)stream;
     switch (a.mlp_mode) {
         case ENARF_MLP_F32: return launch_render<ENARF_MLP_F32>(a, st);

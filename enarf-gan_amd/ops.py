@@ -209,6 +209,19 @@ def query_fwd(points: torch.Tensor, parts: torch.Tensor, canonical_pose: torch.T
 
 
 # ---------------------------------------------------------------------------------------- a13 render
+_render_ws = {}
+
+
+def _render_workspace(dev: torch.device) -> torch.Tensor:
+    """One small queue-head buffer per (device, stream): launches on one stream are ordered, so they can share it."""
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _render_ws.get(key)
+    if ws is None:
+        ws = torch.zeros(max(int(_lib.load().enarf_render_workspace_bytes()), 4) // 4, dtype=torch.int32, device=dev)
+        _render_ws[key] = ws
+    return ws
+
+
 class RenderOutputs:
     __slots__ = ("color", "mask", "disparity", "fine_weights", "fine_depth", "taps", "counters")
 
@@ -271,5 +284,6 @@ def render_fwd(image_coord: torch.Tensor, inv_intrinsics: torch.Tensor, parts: t
     if count:
         o.counters = torch.zeros(4, dtype=torch.int64, device=dev)
         a.counters = _p(o.counters)
+    a.workspace = _p(_render_workspace(dev))
     _lib.check(lib.enarf_render_fwd(C.byref(a), _stream(dev)), "enarf_render_fwd")
     return o

@@ -1,10 +1,12 @@
 #!/bin/bash
 mkdir -p gpurun_out
+python -m pytest tests -m gpu -q -x 2>&1 | tee gpurun_out/pytest_gpu.log | tail -6
 B="python bench.py --steps 60 --warmup 5 --no-cpu-baseline"
 E="python tools/exline.py"
 {
-$B 2>/dev/null | $E strided_rpw8
-ENARF_NO_STRIDE=1 $B 2>/dev/null | $E nostride_rpw8
-for r in 4 16 32 64; do ENARF_RAYS_PER_WG=$r $B 2>/dev/null | $E strided_rpw$r; done
-$B --batch 8 2>/dev/null | $E batch8
-} | tee gpurun_out/exp2.log
+$B 2>/dev/null | $E queue_3percu
+for w in 2 4 6; do ENARF_WGS_PER_CU=$w $B 2>/dev/null | $E queue_wgs$w; done
+for a in 1 3 7; do ENARF_ABLATE=$a $B 2>/dev/null | $E queue_ablate$a; done
+$B --batch 8 2>/dev/null | $E queue_batch8
+$B --batch 32 --steps 20 2>/dev/null | $E queue_batch32
+} | tee gpurun_out/exp5.log

@@ -193,8 +193,12 @@ typedef struct {
     float *dbg_bins;                      /* (B, n, Nf) the bins actually used */
     unsigned long long *counters;         /* [0] valid (part,point) pairs sampled, [1] MLP tiles of 16 points run,
                                              [2] rays marched; atomically accumulated; NULL = not counted */
+    void *workspace;                      /* device, >= enarf_render_workspace_bytes(): the ray queue head. The call
+                                             zeroes it on `stream` (hipMemsetAsync) before the launch; one
+                                             workspace must not be shared by launches that can overlap. */
 } enarf_render_args;
 
+size_t enarf_render_workspace_bytes(void);
 int enarf_render_fwd(const enarf_render_args *args, enarf_stream_t stream);
 
 #ifdef __cplusplus
