@@ -77,7 +77,7 @@ SIGNATURES = {
     "enarf_prepare": (C.c_int, [C.POINTER(PrepareArgs), C.c_void_p]),
     "enarf_mlp_unpack": (C.c_int, [C.c_void_p, _f32p, C.c_void_p]),
     "enarf_query_fwd": (C.c_int, [C.POINTER(QueryArgs), C.c_void_p]),
-    "enarf_render_workspace_bytes": (C.c_size_t, []),
+    "enarf_render_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "enarf_render_fwd": (C.c_int, [C.POINTER(RenderArgs), C.c_void_p]),
 }
 

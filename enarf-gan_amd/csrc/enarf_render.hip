@@ -318,53 +318,30 @@ __device__ __forceinline__ int build_cand_list(int *list, uint32_t set, int lane
     return __popc(set);
 }
 
-// scratch layout (floats) of the render kernel
-constexpr int SC_DTAB = 0;       // 32 range-test depths
-constexpr int SC_BTAB = 32;      // Nc + 1 bin edges (<= 65)
-constexpr int SC_RED = 100;      // 8 partial min/max + near/far
-constexpr int SC_CAND = 112;     // 4 waves x 32 ints
-constexpr int SC_CH = 240;       // coarse: sigma head [64]
-constexpr int SC_CBITS = 304;    // coarse: bits [64]
-constexpr int SC_CWMAX = 368;    // coarse: wmax [64]
-constexpr int SC_FH = 432;       // fine: head [4][64]
-constexpr int SC_FBITS = 688;    // fine: bits [64]
-constexpr int SC_FWMAX = 752;    // fine: wmax [64]
-constexpr int SC_QUEUE = 816;    // 2 ray ids (current / prefetched)
-static_assert(SC_QUEUE + 2 <= kScratchFloats, "scratch overflow");
+// =================================================================================================
+// ray set-up pre-pass: depth range, candidate parts and the compacted list of rays to march
+// =================================================================================================
+// workspace layout: [0] queue head (u32), [1] number of live rays (u32), 64-byte header; then one 16-byte record
+// per ray {depth_min, depth_max, candidate part bits, valid}; then the list of live ray ids (u32).
+struct RayRec { float dmin, dmax; uint32_t cand, valid; };
+__host__ __device__ inline size_t ws_records_off() { return 64; }
+__host__ __device__ inline size_t ws_list_off(long long total_rays) { return 64 + (size_t)total_rays * sizeof(RayRec); }
 
-template <int MODE>
-__global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kernel(const enarf_render_args a, int ablate) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // Persistent workgroups pull consecutive ray ids (over all images) from one atomic queue head: perfect load
-    // balance whatever the mix of hit / miss rays, and at any moment the whole chip works on a window of a few
-    // image rows, whose tri-plane footprint stays in every XCD's L2.
-    const int P = a.P, Nc = a.Nc, Nf = a.Nf, n = a.n;
-    const long long total_rays = (long long)a.B * n;
-    unsigned int *queue = reinterpret_cast<unsigned int *>(a.workspace);
-
-    QueryCtx S;
-    float *scratch = lds + (lds_total_floats<MODE>(P) - kScratchFloats);
-    int *l_q = reinterpret_cast<int *>(scratch + SC_QUEUE);
-    if (tid == 0) l_q[0] = (int)atomicAdd(queue, 1u);
-    __syncthreads();
-    long long cur = (unsigned int)l_q[0];
-    if (cur >= total_rays) return;            // uniform: more workgroups than rays
-    int b = (int)(cur / n);
-    stage_common<MODE>(lds, S, scratch, reinterpret_cast<const char *>(a.mlp_pack) + (size_t)b * kPackBytes,
-                       a.parts + (size_t)b * P * kPartStride, a.canonical_pose, P, tid, 256);
-    S.feat = a.feat_cl + (size_t)b * a.feat_batch_stride;
-    S.mask = a.mask_planes + (size_t)b * a.mask_batch_stride;
-    S.H = a.H; S.W = a.W; S.P = P; S.mult_w = a.multiply_density_with_weight;
-    S.ablate = ablate;
-    float *l_dtab = scratch + SC_DTAB, *l_btab = scratch + SC_BTAB, *l_red = scratch + SC_RED;
-    int *l_cand = reinterpret_cast<int *>(scratch + SC_CAND) + wave * 32;
-    float *l_ch = scratch + SC_CH, *l_cwmax = scratch + SC_CWMAX, *l_fh = scratch + SC_FH, *l_fwmax = scratch + SC_FWMAX;
-    uint32_t *l_cbits = reinterpret_cast<uint32_t *>(scratch + SC_CBITS);
-    uint32_t *l_fbits = reinterpret_cast<uint32_t *>(scratch + SC_FBITS);
-
-    // ---- batch-global near / far planes (rendering.py:15-17): min / max of every part centre's z
-    {
+// decide_frustrum_range (rendering.py:10-79) for every ray, 4 adjacent lanes per ray: the quad splits the parts
+// for the conservative slab tests and the 32 range-test depths (8 each) for the exact cube tests. Rays the
+// reference drops (batch 1, no cube hit: rendering.py:107-110, :337-350) get their zero outputs here and never
+// enter the march; all others are appended to the live list in blocks that keep image order.
+__global__ __launch_bounds__(256) void ray_setup_kernel(const enarf_render_args a, int blocks_per_image) {
+    __shared__ __attribute__((aligned(16))) float l_parts[ENARF_MAX_PARTS * kLdsPartStride];
+    __shared__ float l_dtab[32];
+    __shared__ float l_red[12];
+    __shared__ int l_cnt[5];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = tid & 3;
+    const int b = blockIdx.x / blocks_per_image, blk = blockIdx.x % blocks_per_image;
+    const int P = a.P, n = a.n, Nf = a.Nf;
+    for (int i = tid; i < P * kPartStride; i += 256)
+        l_parts[(i / kPartStride) * kLdsPartStride + (i % kPartStride)] = a.parts[(size_t)b * P * kPartStride + i];
+    {   // batch-global near / far planes (rendering.py:15-17): min / max of every part centre's z
         float mn = 3.0e38f, mx = -3.0e38f;
         for (int i = tid; i < a.B * P; i += 256) {
             const float z = a.parts[(size_t)i * kPartStride + 11];
@@ -386,6 +363,135 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
     }
     const float near_p = l_red[8], far_p = l_red[9];
     if (tid < 32) l_dtab[tid] = linspace_sym(near_p, far_p, 32, tid);
+    __syncthreads();
+
+    const int ray = blk * 64 + (tid >> 2);
+    const bool in_range = ray < n;
+    const int rc = in_range ? ray : n - 1;
+    const float *coord = a.image_coord + (size_t)b * 3 * n;
+    const float *Ki = a.inv_intrinsics + (size_t)b * 9;
+    const float u = coord[rc], v = coord[n + rc], w = coord[2 * n + rc];
+    const float dx = exact_dot3(Ki[0], u, Ki[1], v, Ki[2], w);
+    const float dy = exact_dot3(Ki[3], u, Ki[4], v, Ki[5], w);
+    const float dz = exact_dot3(Ki[6], u, Ki[7], v, Ki[8], w);
+
+    // parts the ray can touch between near and far (conservative), split over the quad
+    uint32_t mine = 0;
+    for (int k = g; k < P; k += 4)
+        if (ray_hits_part(l_parts + k * kLdsPartStride, dx, dy, dz, near_p, far_p)) mine |= 1u << k;
+    uint32_t cand_all = mine | (uint32_t)quad_perm_i<0xB1>((int)mine);
+    cand_all |= (uint32_t)quad_perm_i<0x4E>((int)cand_all);
+
+    // exact range test: this lane's 8 of the 32 depths x candidate parts
+    float mn = 1.0e3f, mx = -1.0e3f;
+    for (int di = g * 8; di < g * 8 + 8; ++di) {
+        const float ds = l_dtab[di];
+        const float qx = exact_mul(dx, ds), qy = exact_mul(dy, ds), qz = exact_mul(dz, ds);
+        bool inside = false;
+        uint32_t m = cand_all;
+        while (m) {
+            const int k = __builtin_ctz(m);
+            m &= m - 1;
+            float lx, ly, lz;
+            exact_local(l_parts + k * kLdsPartStride, qx, qy, qz, lx, ly, lz);
+            inside = inside || in_unit_cube_incl(lx, ly, lz);
+        }
+        if (inside) { mn = fminf(mn, ds); mx = fmaxf(mx, ds); }
+    }
+    mn = fminf(mn, quad_perm_f<0xB1>(mn)); mn = fminf(mn, quad_perm_f<0x4E>(mn));
+    mx = fmaxf(mx, quad_perm_f<0xB1>(mx)); mx = fmaxf(mx, quad_perm_f<0x4E>(mx));
+    const bool ray_valid = (mn != 1.0e3f);
+    float dmin = ray_valid ? mn : near_p;
+    const float dmax = (mx != -1.0e3f) ? mx : far_p;
+    dmin = fmaxf(dmin, near_p);
+    const bool live = in_range && (ray_valid || !a.drop_invalid_rays);
+
+    // parts over the marched segment only
+    uint32_t mine2 = 0;
+    for (int k = g; k < P; k += 4)
+        if (((cand_all >> k) & 1u) && ray_hits_part(l_parts + k * kLdsPartStride, dx, dy, dz, dmin, dmax)) mine2 |= 1u << k;
+    uint32_t cand = mine2 | (uint32_t)quad_perm_i<0xB1>((int)mine2);
+    cand |= (uint32_t)quad_perm_i<0x4E>((int)cand);
+
+    const size_t rid = (size_t)b * n + rc;
+    if (in_range && g == 0) {
+        RayRec *recs = reinterpret_cast<RayRec *>(reinterpret_cast<char *>(a.workspace) + ws_records_off());
+        recs[rid] = RayRec{dmin, dmax, cand, ray_valid ? 1u : 0u};
+        if (a.dbg_depth_min) {
+            a.dbg_depth_min[rid] = dmin;
+            a.dbg_depth_max[rid] = dmax;
+            a.dbg_ray_valid[rid] = ray_valid ? 1 : 0;
+        }
+    }
+    if (in_range && !live) {   // dropped ray: zeros (rendering.py:337-350)
+        if (g < 3) a.color[((size_t)b * 3 + g) * n + ray] = 0.0f;
+        if (g == 3) { a.mask[rid] = 0.0f; a.disparity[rid] = 0.0f; }
+        if (a.fine_weights) for (int i = g; i < Nf - 1; i += 4) a.fine_weights[rid * (Nf - 1) + i] = 0.0f;
+        if (a.fine_depth) for (int i = g; i < Nf; i += 4) a.fine_depth[rid * Nf + i] = 0.0f;
+    }
+    // append the block's live rays, in ray order, to the list
+    const uint64_t bal = __ballot(live && g == 0);
+    if (lane == 0) l_cnt[wave] = __popcll(bal);
+    __syncthreads();
+    if (tid == 0) {
+        const int tot = l_cnt[0] + l_cnt[1] + l_cnt[2] + l_cnt[3];
+        l_cnt[4] = tot ? (int)atomicAdd(reinterpret_cast<unsigned int *>(a.workspace) + 1, (unsigned int)tot) : 0;
+    }
+    __syncthreads();
+    if (live && g == 0) {
+        int pos = l_cnt[4] + __popcll(bal & ((1ull << lane) - 1ull));
+        for (int wv = 0; wv < wave; ++wv) pos += l_cnt[wv];
+        uint32_t *list = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(a.workspace) + ws_list_off((long long)a.B * n));
+        list[pos] = (uint32_t)rid;
+    }
+}
+
+// scratch layout (floats) of the render kernel
+// (floats 0..31 and 100..111 are free)
+constexpr int SC_BTAB = 32;      // Nc + 1 bin edges (<= 65)
+constexpr int SC_CAND = 112;     // 4 waves x 32 ints
+constexpr int SC_CH = 240;       // coarse: sigma head [64]
+constexpr int SC_CBITS = 304;    // coarse: bits [64]
+constexpr int SC_CWMAX = 368;    // coarse: wmax [64]
+constexpr int SC_FH = 432;       // fine: head [4][64]
+constexpr int SC_FBITS = 688;    // fine: bits [64]
+constexpr int SC_FWMAX = 752;    // fine: wmax [64]
+constexpr int SC_QUEUE = 816;    // 2 ray ids (current / prefetched)
+static_assert(SC_QUEUE + 2 <= kScratchFloats, "scratch overflow");
+
+template <int MODE>
+__global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kernel(const enarf_render_args a, int ablate) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // Persistent workgroups pull consecutive entries of the live-ray list (built by ray_setup_kernel, in image
+    // order) from one atomic queue head: perfect load balance whatever the mix of heavy and light rays, and at any
+    // moment the whole chip works on a window of a few image rows, whose tri-plane footprint stays in every XCD's L2.
+    const int P = a.P, Nc = a.Nc, Nf = a.Nf, n = a.n;
+    unsigned int *queue = reinterpret_cast<unsigned int *>(a.workspace);
+    const long long total_live = (long long)queue[1];
+    const RayRec *recs = reinterpret_cast<const RayRec *>(reinterpret_cast<const char *>(a.workspace) + ws_records_off());
+    const uint32_t *live_list = reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(a.workspace) +
+                                                                  ws_list_off((long long)a.B * n));
+
+    QueryCtx S;
+    float *scratch = lds + (lds_total_floats<MODE>(P) - kScratchFloats);
+    int *l_q = reinterpret_cast<int *>(scratch + SC_QUEUE);
+    if (tid == 0) l_q[0] = (int)atomicAdd(queue, 1u);
+    __syncthreads();
+    long long cur = (unsigned int)l_q[0];
+    if (cur >= total_live) return;            // uniform: more workgroups than live rays
+    int b = (int)(live_list[cur] / (uint32_t)n);
+    stage_common<MODE>(lds, S, scratch, reinterpret_cast<const char *>(a.mlp_pack) + (size_t)b * kPackBytes,
+                       a.parts + (size_t)b * P * kPartStride, a.canonical_pose, P, tid, 256);
+    S.feat = a.feat_cl + (size_t)b * a.feat_batch_stride;
+    S.mask = a.mask_planes + (size_t)b * a.mask_batch_stride;
+    S.H = a.H; S.W = a.W; S.P = P; S.mult_w = a.multiply_density_with_weight;
+    S.ablate = ablate;
+    float *l_btab = scratch + SC_BTAB;
+    int *l_cand = reinterpret_cast<int *>(scratch + SC_CAND) + wave * 32;
+    float *l_ch = scratch + SC_CH, *l_cwmax = scratch + SC_CWMAX, *l_fh = scratch + SC_FH, *l_fwmax = scratch + SC_FWMAX;
+    uint32_t *l_cbits = reinterpret_cast<uint32_t *>(scratch + SC_CBITS);
+    uint32_t *l_fbits = reinterpret_cast<uint32_t *>(scratch + SC_FBITS);
     if (tid <= Nc) l_btab[tid] = linspace_sym(0.0f, 1.0f, Nc + 1, tid);
     __syncthreads();
 
@@ -396,10 +502,11 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
     const int j4 = lane >> 2;                              // this lane's sample within the wave's tile
     const bool dbgq = (a.dbg_fine_density != nullptr);
 
-    while (cur < total_rays) {
-        if (tid == 0) l_q[qslot ^ 1] = (int)atomicAdd(queue, 1u);   // prefetch the next id; read after the S0 barrier
-        const int nb = (int)(cur / n), ray = (int)(cur - (long long)nb * n);
-        if (nb != b) {   // next image: restage its MLP pack and part frames (ids are consecutive, so this is rare)
+    while (cur < total_live) {
+        if (tid == 0) l_q[qslot ^ 1] = (int)atomicAdd(queue, 1u);   // prefetch the next entry; read after the S1 barrier
+        const uint32_t rid = live_list[cur];
+        const int nb = (int)(rid / (uint32_t)n), ray = (int)(rid - (uint32_t)nb * (uint32_t)n);
+        if (nb != b) {   // next image: restage its MLP pack and part frames (the list is in image order, so this is rare)
             b = nb;
             __syncthreads();
             stage_common<MODE>(lds, S, scratch, reinterpret_cast<const char *>(a.mlp_pack) + (size_t)b * kPackBytes,
@@ -415,58 +522,11 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
         const float dx = exact_dot3(Ki[0], u, Ki[1], v, Ki[2], w);
         const float dy = exact_dot3(Ki[3], u, Ki[4], v, Ki[5], w);
         const float dz = exact_dot3(Ki[6], u, Ki[7], v, Ki[8], w);
-
-        // ---- S0: depth range (rendering.py:40-70): 32 depths x candidate parts, all 256 threads.
-        // Each wave keeps a private list of the parts the ray can touch in [near, far]; half-wave
-        // (depth = tid & 31, slot = tid >> 5) tests candidates slot, slot + 8, ...
-        const uint32_t cand_all = (uint32_t)__ballot(lane < P && ray_hits_part(S.parts + min(lane, P - 1) * kLdsPartStride,
-                                                                              dx, dy, dz, near_p, far_p));
-        const int ncand_all = build_cand_list(l_cand, cand_all, lane);
-        float dmin, dmax;
-        bool ray_valid;
-        {
-            const float ds = l_dtab[tid & 31];
-            const float qx = exact_mul(dx, ds), qy = exact_mul(dy, ds), qz = exact_mul(dz, ds);
-            bool inside = false;
-            for (int i = tid >> 5; i < ncand_all; i += 8) {
-                float lx, ly, lz;
-                exact_local(S.parts + l_cand[i] * kLdsPartStride, qx, qy, qz, lx, ly, lz);
-                inside = inside || in_unit_cube_incl(lx, ly, lz);
-            }
-            const float mn = wave_min(inside ? ds : 1.0e3f), mx = wave_max(inside ? ds : -1.0e3f);
-            if (lane == 0) { l_red[wave] = mn; l_red[4 + wave] = mx; }
-            __syncthreads();
-            dmin = fminf(fminf(l_red[0], l_red[1]), fminf(l_red[2], l_red[3]));
-            dmax = fmaxf(fmaxf(l_red[4], l_red[5]), fmaxf(l_red[6], l_red[7]));
-            ray_valid = (dmin != 1.0e3f);
-            dmin = ray_valid ? dmin : near_p;
-            dmax = (dmax != -1.0e3f) ? dmax : far_p;
-            dmin = fmaxf(dmin, near_p);
-        }
-        const long long next_ray = (unsigned int)l_q[qslot ^ 1];
-        qslot ^= 1;
-        if (a.dbg_depth_min && tid == 0) {
-            a.dbg_depth_min[(size_t)b * n + ray] = dmin;
-            a.dbg_depth_max[(size_t)b * n + ray] = dmax;
-            a.dbg_ray_valid[(size_t)b * n + ray] = ray_valid ? 1 : 0;
-        }
-        if (a.drop_invalid_rays && !ray_valid) {   // rendering.py:107-110 / :337-350: zeros
-            if (wave == 0) {
-                if (lane < 3) a.color[((size_t)b * 3 + lane) * n + ray] = 0.0f;
-                if (lane == 3) a.mask[(size_t)b * n + ray] = 0.0f;
-                if (lane == 4) a.disparity[(size_t)b * n + ray] = 0.0f;
-                if (a.fine_weights && lane < Nf - 1) a.fine_weights[((size_t)b * n + ray) * (Nf - 1) + lane] = 0.0f;
-                if (a.fine_depth && lane < Nf) a.fine_depth[((size_t)b * n + ray) * Nf + lane] = 0.0f;
-            }
-            __syncthreads();   // l_red is rewritten by the next ray
-            cur = next_ray;
-            continue;
-        }
+        // depth range and candidate parts: from the set-up pre-pass
+        const RayRec rec = recs[rid];
+        const float dmin = rec.dmin, dmax = rec.dmax;
         if (wave == 0) n_rays += 1;
-        // candidate parts over the marched segment only
-        const uint32_t cand = (uint32_t)__ballot(lane < P && ((cand_all >> lane) & 1u) &&
-                                                 ray_hits_part(S.parts + min(lane, P - 1) * kLdsPartStride, dx, dy, dz, dmin, dmax));
-        const int ncand = build_cand_list(l_cand, cand, lane);
+        const int ncand = build_cand_list(l_cand, rec.cand, lane);
         const float sx = exact_mul(dmin, dx), sy = exact_mul(dmin, dy), sz = exact_mul(dmin, dz);
         const float ex = exact_mul(dmax, dx), ey = exact_mul(dmax, dy), ez = exact_mul(dmax, dz);
 
@@ -488,6 +548,8 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
             if (active && (lane & 3) == 0) { l_cbits[i] = bits; l_cwmax[i] = wmax; }
         }
         __syncthreads();
+        const long long next_ray = (unsigned int)l_q[qslot ^ 1];
+        qslot ^= 1;
 
         // ---- S2 (every wave, lane = sample): weights (rendering.py:180-184), smoothing (:187-190), bins (:192-197)
         float bin;
@@ -509,13 +571,18 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
             if (a.bins) {
                 bin = a.bins[((size_t)b * n + ray) * Nf + min(lane, Nf - 1)];
             } else {
+                // Importance samples = Nf iid draws from the piecewise-constant pdf, sorted (rendering.py:192-197).
+                // Sorted uniforms come directly from exponential spacings (u_(i) = E_1+..+E_i / E_1+..+E_{Nf+1}),
+                // each is pushed through the inverse CDF (monotone, so the bins come out sorted): bin index by
+                // binary search, position inside the bin by the leftover - the same law as multinomial + U/Nc.
                 const float cdf = wave_scan_incl(ws, lane);
                 const float total = __shfl(cdf, Nc - 1);
                 uint32_t rnd[4];
-                const uint64_t gid = (uint64_t)b * (uint64_t)n + (uint64_t)ray;
-                philox4x32((uint32_t)gid, (uint32_t)(gid >> 32), (uint32_t)lane, 0x454E4152u,
-                           (uint32_t)a.seed, (uint32_t)(a.seed >> 32), rnd);
-                const float target = u32_to_unit(rnd[0]) * total;
+                philox4x32(rid, 0u, (uint32_t)lane, 0x454E4152u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), rnd);
+                const float e = (lane < Nf) ? -__logf(1.0f - u32_to_unit(rnd[0])) : 0.0f;
+                const float esum = wave_scan_incl(e, lane);
+                const float etot = __shfl(esum, 63) - __logf(1.0f - u32_to_unit(__shfl((int)rnd[1], 0)));
+                const float target = fminf(esum / etot, 0.99999994f) * total;
                 int lo = 0, hi = Nc - 1;   // smallest i with cdf[i] > target
 #pragma unroll
                 for (int it = 0; it < 6; ++it) {
@@ -523,8 +590,10 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
                     const float c = __shfl(cdf, mid);
                     if (lo < hi) { if (c > target) hi = mid; else lo = mid + 1; }
                 }
-                const float raw = (float)lo / (float)Nc + u32_to_unit(rnd[1]) / (float)Nc;
-                bin = wave_sort64(lane < Nf ? raw : 3.0e38f, lane);
+                const float c_hi = __shfl(cdf, lo), c_lo = __shfl(cdf, max(lo - 1, 0));
+                const float below = (lo > 0) ? c_lo : 0.0f;
+                const float frac = fminf(fmaxf((target - below) / (c_hi - below), 0.0f), 0.99999994f);
+                bin = (lane < Nf) ? ((float)lo + frac) / (float)Nc : 3.0e38f;
             }
             if (a.dbg_bins && lane < Nf && wave == 0) a.dbg_bins[((size_t)b * n + ray) * Nf + lane] = bin;
         }
@@ -585,9 +654,8 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
             if (a.fine_weights && seg) a.fine_weights[((size_t)b * n + ray) * (Nf - 1) + lane] = wgt;
             if (a.fine_depth && lane < Nf) a.fine_depth[((size_t)b * n + ray) * Nf + lane] = fdepth;
         }
-        // no barrier needed here: the next ray's S0 barrier comes before anything this wave reads is rewritten
-        // (coarse arrays are rewritten in S1', fine arrays in S3', l_red before the S0' barrier - and wave 0 reads
-        // l_red only right after that barrier).
+        // no barrier needed here: coarse arrays are rewritten in S1' (after this ray's S3 barrier, which follows every
+        // wave's S2 reads), fine arrays in S3' (after the S1' barrier, which wave 0 reaches only after this S4).
         cur = next_ray;
     }
     if (a.counters && lane == 0) {
@@ -697,11 +765,18 @@ static int launch_render(const enarf_render_args &a, hipStream_t st) {
     const char *ab = getenv("ENARF_ABLATE");      // diagnosis only: 1 skip feature gathers, 2 skip mask planes, 4 skip MLP
     hipError_t e = hipMemsetAsync(a.workspace, 0, 64, st);
     if (e != hipSuccess) return host::fail((int)e, "enarf_render_fwd: hipMemsetAsync(workspace) failed: %s", hipGetErrorString(e));
+    const int bpi = (a.n + 63) / 64;
+    hipLaunchKernelGGL(ray_setup_kernel, dim3((unsigned)(bpi * a.B)), dim3(256), 0, st, a, bpi);
+    if (int rc = host::check_launch("enarf_render_fwd(ray set-up)")) return rc;
     hipLaunchKernelGGL(render_kernel<MODE>, dim3((unsigned)wgs), dim3(256), lds, st, a, ab ? atoi(ab) : 0);
     return host::check_launch("enarf_render_fwd");
 }
 
-extern "C" size_t enarf_render_workspace_bytes(void) { return 64; }
+extern "C" size_t enarf_render_workspace_bytes(int B, int n) {
+    if (B <= 0 || n <= 0) return 0;
+    const long long total = (long long)B * n;
+    return (ws_list_off(total) + (size_t)total * sizeof(uint32_t) + 63) & ~(size_t)63;
+}
 
 extern "C" int enarf_render_fwd(const enarf_render_args *args, enarf_stream_t stream) {
     if (!args) return host::fail(ENARF_ERR_ARG, "enarf_render_fwd: args is null");
@@ -716,7 +791,7 @@ extern "C" int enarf_render_fwd(const enarf_render_args *args, enarf_stream_t st
                                                  "(one lane per sample)", a.Nc, a.Nf);
     if (a.dbg_depth_min && (!a.dbg_depth_max || !a.dbg_ray_valid))
         return host::fail(ENARF_ERR_ARG, "enarf_render_fwd: dbg_depth_min needs dbg_depth_max and dbg_ray_valid");
-    if ((long long)a.n * a.B > 0x7FFFFFF0ll) return host::fail(ENARF_ERR_UNSUPPORTED, "enarf_render_fwd: more than 2^31 rays in one launch");
+    if ((long long)((a.n + 63) / 64) * a.B > 0x7FFFFFFFll || (long long)a.n * a.B > 0x7FFFFFF0ll) return host::fail(ENARF_ERR_UNSUPPORTED, "enarf_render_fwd: more than 2^31 rays in one launch");
     if (!a.workspace) return host::fail(ENARF_ERR_ARG, "enarf_render_fwd: workspace is null (enarf_render_workspace_bytes() bytes of device memory)");
     hipStream_t st = (hipStream_t)stream;
     switch (a.mlp_mode) {

@@ -212,12 +212,14 @@ def query_fwd(points: torch.Tensor, parts: torch.Tensor, canonical_pose: torch.T
 _render_ws = {}
 
 
-def _render_workspace(dev: torch.device) -> torch.Tensor:
-    """One small queue-head buffer per (device, stream): launches on one stream are ordered, so they can share it."""
+def _render_workspace(dev: torch.device, B: int, n: int) -> torch.Tensor:
+    """Workspace of enarf_render_fwd, cached per (device, stream): launches on one stream are ordered, so they can
+    share it; it only grows."""
     key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    need = int(_lib.load().enarf_render_workspace_bytes(B, n))
     ws = _render_ws.get(key)
-    if ws is None:
-        ws = torch.zeros(max(int(_lib.load().enarf_render_workspace_bytes()), 4) // 4, dtype=torch.int32, device=dev)
+    if ws is None or ws.numel() * 4 < need:
+        ws = torch.empty((need + 3) // 4, dtype=torch.int32, device=dev)
         _render_ws[key] = ws
     return ws
 
@@ -284,6 +286,6 @@ def render_fwd(image_coord: torch.Tensor, inv_intrinsics: torch.Tensor, parts: t
     if count:
         o.counters = torch.zeros(4, dtype=torch.int64, device=dev)
         a.counters = _p(o.counters)
-    a.workspace = _p(_render_workspace(dev))
+    a.workspace = _p(_render_workspace(dev, B, n))
     _lib.check(lib.enarf_render_fwd(C.byref(a), _stream(dev)), "enarf_render_fwd")
     return o

@@ -152,7 +152,8 @@ typedef struct {
 int enarf_query_fwd(const enarf_query_args *args, enarf_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
- * a13. The fused ray march: one wavefront per ray.
+ * a13. The fused ray march: a small ray set-up launch (depth ranges, live-ray list) then the march itself,
+ * persistent workgroups of 4 wavefronts taking one ray at a time from a queue.
  * Replaces render (libraries/NeRF/rendering.py:227-359) = decide_frustrum_range (:10-79) +
  * coarse_sample (:82-135) + coarse_to_fine_sample (:138-224) + two density/colour queries + alpha
  * compositing (:307-335), including the batch-global near/far planes (:15-17) and, when
@@ -193,12 +194,13 @@ typedef struct {
     float *dbg_bins;                      /* (B, n, Nf) the bins actually used */
     unsigned long long *counters;         /* [0] valid (part,point) pairs sampled, [1] MLP tiles of 16 points run,
                                              [2] rays marched; atomically accumulated; NULL = not counted */
-    void *workspace;                      /* device, >= enarf_render_workspace_bytes(): the ray queue head. The call
-                                             zeroes it on `stream` (hipMemsetAsync) before the launch; one
-                                             workspace must not be shared by launches that can overlap. */
+    void *workspace;                      /* device, >= enarf_render_workspace_bytes(B, n): queue head, per-ray records
+                                             (depth range, candidate parts) and the live-ray list. The call zeroes
+                                             the header on `stream` (hipMemsetAsync); one workspace must not be
+                                             shared by launches that can overlap. */
 } enarf_render_args;
 
-size_t enarf_render_workspace_bytes(void);
+size_t enarf_render_workspace_bytes(int B, int n);
 int enarf_render_fwd(const enarf_render_args *args, enarf_stream_t stream);
 
 #ifdef __cplusplus
