@@ -321,7 +321,7 @@ __device__ __forceinline__ int build_cand_list(int *list, uint32_t set, int lane
 // =================================================================================================
 // ray set-up pre-pass: depth range, candidate parts and the compacted list of rays to march
 // =================================================================================================
-// workspace layout: [0] queue head (u32), [1] number of live rays (u32), 64-byte header; then one 16-byte record
+// workspace layout: 64-byte header: [0] unused, [1] number of live rays, [2..9] the 8 per-XCD queue heads (u32); then one 16-byte record
 // per ray {depth_min, depth_max, candidate part bits, valid}; then the list of live ray ids (u32).
 struct RayRec { float dmin, dmax; uint32_t cand, valid; };
 __host__ __device__ inline size_t ws_records_off() { return 64; }
@@ -446,6 +446,21 @@ __global__ __launch_bounds__(256) void ray_setup_kernel(const enarf_render_args 
     }
 }
 
+// ---- XCD-affine ray queues ---------------------------------------------------------------------------------------
+// The live-ray list is cut into blocks of kQBlock consecutive entries that are dealt round-robin to 8 queues, one
+// per XCD; a workgroup pulls from the queue of the XCD it runs on (HW_REG_XCC_ID). Neighbouring rays - which touch
+// neighbouring tri-plane texels - are then marched on ONE XCD and share its L2, instead of every XCD pulling the
+// whole window's footprint through its own L2. Placement only affects speed: any workgroup may serve any queue.
+constexpr int kQBlock = 32;
+constexpr int kQueues = 8;
+__device__ __forceinline__ int xcc_id() {
+    return (int)(__builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11)) & 0xF);   // HW_REG_XCC_ID[3:0]
+}
+// j-th dequeue of queue x -> index into the live list (may be >= total: then the queue is drained)
+__device__ __forceinline__ long long queue_entry(unsigned int j, int x) {
+    return ((long long)(j / kQBlock) * kQueues + x) * kQBlock + (j % kQBlock);
+}
+
 // scratch layout (floats) of the render kernel
 // (floats 0..31 and 100..111 are free)
 constexpr int SC_BTAB = 32;      // Nc + 1 bin edges (<= 65)
@@ -467,8 +482,10 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
     // order) from one atomic queue head: perfect load balance whatever the mix of heavy and light rays, and at any
     // moment the whole chip works on a window of a few image rows, whose tri-plane footprint stays in every XCD's L2.
     const int P = a.P, Nc = a.Nc, Nf = a.Nf, n = a.n;
-    unsigned int *queue = reinterpret_cast<unsigned int *>(a.workspace);
-    const long long total_live = (long long)queue[1];
+    unsigned int *wsh = reinterpret_cast<unsigned int *>(a.workspace);
+    const long long total_live = (long long)wsh[1];
+    const int my_q = xcc_id() & (kQueues - 1);
+    unsigned int *queue = wsh + 2 + my_q;                   // this XCD's queue head
     const RayRec *recs = reinterpret_cast<const RayRec *>(reinterpret_cast<const char *>(a.workspace) + ws_records_off());
     const uint32_t *live_list = reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(a.workspace) +
                                                                   ws_list_off((long long)a.B * n));
@@ -478,8 +495,8 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
     int *l_q = reinterpret_cast<int *>(scratch + SC_QUEUE);
     if (tid == 0) l_q[0] = (int)atomicAdd(queue, 1u);
     __syncthreads();
-    long long cur = (unsigned int)l_q[0];
-    if (cur >= total_live) return;            // uniform: more workgroups than live rays
+    long long cur = queue_entry((unsigned int)l_q[0], my_q);
+    if (cur >= total_live) return;            // uniform: this XCD's queue is already drained
     int b = (int)(live_list[cur] / (uint32_t)n);
     stage_common<MODE>(lds, S, scratch, reinterpret_cast<const char *>(a.mlp_pack) + (size_t)b * kPackBytes,
                        a.parts + (size_t)b * P * kPartStride, a.canonical_pose, P, tid, 256);
@@ -548,7 +565,7 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
             if (active && (lane & 3) == 0) { l_cbits[i] = bits; l_cwmax[i] = wmax; }
         }
         __syncthreads();
-        const long long next_ray = (unsigned int)l_q[qslot ^ 1];
+        const long long next_ray = queue_entry((unsigned int)l_q[qslot ^ 1], my_q);
         qslot ^= 1;
 
         // ---- S2 (every wave, lane = sample): weights (rendering.py:180-184), smoothing (:187-190), bins (:192-197)
