@@ -174,7 +174,7 @@ __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf
 
 // StyledConv activation: LeakyReLU(0.2) * sqrt(2)   (libraries/custom_stylegan2/net.py:318)
 __device__ __forceinline__ float styled_act(float v) {
-    return (v >= 0.0f ? v : 0.2f * v) * 1.41421356237309515f;
+    return fmaxf(v, 0.2f * v) * 1.41421356237309515f;      // max(v, 0.2 v) == leaky_relu(v, 0.2)
 }
 
 // ---- bf16 helpers -------------------------------------------------------------------------------

@@ -174,12 +174,16 @@ __device__ __forceinline__ f32x4 mlp_tile_bf16(const float *__restrict__ Bp, con
 }
 
 // split-fp16: same structure, 11-bit halves -> ~2^-21 relative
+// hi = f16 round-toward-zero (v_cvt_pkrtz_f16_f32: two values per instruction, saturates at +-65504 instead of
+// overflowing), lo = f16(x - hi): x - hi is exact in fp32 and fits 11 bits to ~2^-21 |x|
 __device__ __forceinline__ void split8h(const float v[8], f16x8 &hi, f16x8 &lo) {
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const _Float16 h = f32_to_f16_sat(v[i]);
-        hi[i] = h;
-        lo[i] = f32_to_f16_sat(v[i] - (float)h);
+    for (int i = 0; i < 8; i += 2) {
+        const f16x2 h = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(v[i], v[i + 1]));
+        const f16x2 l = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(v[i] - (float)h[0], v[i + 1] - (float)h[1]));
+        hi[i] = h[0]; hi[i + 1] = h[1];
+        lo[i] = l[0]; lo[i + 1] = l[1];
     }
 }
 __device__ __forceinline__ f32x4 mma_split_h(const short *__restrict__ Ahl, const f16x8 &bh, const f16x8 &bl, f32x4 c,
@@ -337,7 +341,7 @@ __device__ __forceinline__ void query_tile(const QueryCtx &S, const int *cand_li
         // lane g owns plane g: xy, yz, zx (lane 3 repeats plane 0 and is ignored)
         const float qx = (g == 1) ? cy : (g == 2) ? cz : cx;
         const float qy = (g == 1) ? cz : (g == 2) ? cx : cy;
-        const Taps t = make_taps(qx, qy, S.H, S.W);
+        const Taps t = make_taps(qx, qy, S.H, S.W);   // fully clamped: every tap index is in-plane whatever the input
         float sg = 1.0f;
         if (act && g < 3 && !(S.ablate & 2)) {   // part probability plane g (sampling.py:43-48, :62)
             const float *mp = S.mask + (size_t)(3 * k + g) * mplane;

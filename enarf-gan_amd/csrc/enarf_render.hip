@@ -48,15 +48,17 @@ __device__ __forceinline__ void pack_weight_row(float *__restrict__ pf, short *_
 }
 
 __global__ __launch_bounds__(256) void prepare_kernel(const PrepareParams prm) {
+    // grid = (3, B): block (layer, b) packs one layer of image b's MLP; the layer-0 block also writes the part frames
     const enarf_prepare_args &a = prm.a;
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int layer = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const int J = a.num_joints;
     const int P = (a.origin_location == ENARF_ORIGIN_CENTER_HEAD) ? J : J - 1;
     __shared__ float s_style[kHid];
+    __shared__ float s_inv[kHid];
     __shared__ float s_w[kHid * kHid];
 
     // ---- part frames (pose_utils.py:129-148, rendering.py:258-260, narf.py:165)
-    if (a.parts && tid < P) {
+    if (layer == 0 && a.parts && tid < P) {
         const float *pose = a.pose_to_camera + (size_t)b * J * 16;
         float *out = a.parts + ((size_t)b * P + tid) * kPartStride;
         float R[9], t[3], bl;
@@ -90,37 +92,34 @@ __global__ __launch_bounds__(256) void prepare_kernel(const PrepareParams prm) {
     if (!a.mlp_pack) return;
     float *pf = reinterpret_cast<float *>(reinterpret_cast<char *>(a.mlp_pack) + (size_t)b * kPackBytes);
     short *ph = reinterpret_cast<short *>(pf + PK_F32_FLOATS);
-    for (int i = tid; i < PK_F32_FLOATS; i += 256) pf[i] = 0.0f;
-    for (int i = tid; i < 2 * PKH_SHORTS; i += 256) ph[i] = 0;
-    __syncthreads();
+    const int cin = (layer == 0) ? kFeat : kHid;
+    const int cout = (layer == 2) ? 4 : kHid;
+    if (layer == 2) {   // rows 4..15 of the last layer's 16-row operand tiles are zero; layers 0/1 write every element
+        for (int i = tid; i < 16 * 64; i += 256) pf[PK_W3 + i] = 0.0f;
+        for (int i = tid; i < 16; i += 256) pf[PK_B3 + i] = 0.0f;
+        for (int i = tid; i < 2 * 2 * 64 * 8; i += 256) { ph[PKH_W3 + i] = 0; ph[PKH_SHORTS + PKH_W3 + i] = 0; }
+    }
     const float *z = a.z_rend + (size_t)b * a.style_dim;
     const float mscale = 1.0f / sqrtf((float)a.style_dim);
-    for (int layer = 0; layer < 3; ++layer) {
-        const int cin = (layer == 0) ? kFeat : kHid;
-        const int cout = (layer == 2) ? 4 : kHid;
-        if (tid < cin) {   // EqualLinear: z @ (Wm * scale)^T + b_mod
-            const float *wm = a.mod_weight[layer] + (size_t)tid * a.style_dim;
-            float acc = 0.0f;
-            for (int d = 0; d < a.style_dim; ++d) acc += z[d] * (wm[d] * mscale);
-            s_style[tid] = acc + a.mod_bias[layer][tid];
-        }
-        __syncthreads();
-        const float cscale = 1.0f / sqrtf((float)cin);
-        for (int e = tid; e < cout * cin; e += 256) {
-            const int c = e % cin;
-            s_w[e] = (cscale * a.conv_weight[layer][e]) * s_style[c];
-        }
-        __syncthreads();
-        if (tid < cout) {   // F.normalize(dim=-1, eps=1e-12)
-            float ss = 0.0f;
-            for (int c = 0; c < cin; ++c) ss += s_w[tid * cin + c] * s_w[tid * cin + c];
-            const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
-            for (int c = 0; c < cin; ++c) pack_weight_row(pf, ph, layer, tid, c, s_w[tid * cin + c] * inv);
-            const int boff = (layer == 0) ? PK_B1 : (layer == 1) ? PK_B2 : PK_B3;
-            pf[boff + tid] = a.bias[layer][tid];
-        }
-        __syncthreads();
+    if (tid < cin) {   // EqualLinear: z @ (Wm * scale)^T + b_mod
+        const float *wm = a.mod_weight[layer] + (size_t)tid * a.style_dim;
+        float acc = 0.0f;
+        for (int d = 0; d < a.style_dim; ++d) acc += z[d] * (wm[d] * mscale);
+        s_style[tid] = acc + a.mod_bias[layer][tid];
     }
+    __syncthreads();
+    const float cscale = 1.0f / sqrtf((float)cin);
+    for (int e = tid; e < cout * cin; e += 256) s_w[e] = (cscale * a.conv_weight[layer][e]) * s_style[e % cin];
+    __syncthreads();
+    if (tid < cout) {   // F.normalize(dim=-1, eps=1e-12)
+        float ss = 0.0f;
+        for (int c = 0; c < cin; ++c) ss += s_w[tid * cin + c] * s_w[tid * cin + c];
+        s_inv[tid] = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+        const int boff = (layer == 0) ? PK_B1 : (layer == 1) ? PK_B2 : PK_B3;
+        pf[boff + tid] = a.bias[layer][tid];
+    }
+    __syncthreads();
+    for (int e = tid; e < cout * cin; e += 256) pack_weight_row(pf, ph, layer, e / cin, e % cin, s_w[e] * s_inv[e / cin]);
 }
 
 __global__ void mlp_unpack_kernel(const float *__restrict__ pf, float *__restrict__ dense) {
@@ -696,6 +695,7 @@ extern "C" size_t enarf_mlp_pack_bytes(void) { return kPackBytes; }
 extern "C" int enarf_prepare(const enarf_prepare_args *args, enarf_stream_t stream) {
     if (!args) return host::fail(ENARF_ERR_ARG, "enarf_prepare: args is null");
     const enarf_prepare_args &a = *args;
+    if (a.B > 65535) return host::fail(ENARF_ERR_UNSUPPORTED, "enarf_prepare: B > 65535");
     if (a.B <= 0 || a.num_joints < 2 || a.num_joints > ENARF_MAX_JOINTS || a.style_dim <= 0)
         return host::fail(ENARF_ERR_ARG, "enarf_prepare: bad sizes (B=%d joints=%d style_dim=%d)", a.B, a.num_joints, a.style_dim);
     if (a.origin_location < 0 || a.origin_location > 2) return host::fail(ENARF_ERR_ARG, "enarf_prepare: bad origin_location %d", a.origin_location);
@@ -713,7 +713,7 @@ extern "C" int enarf_prepare(const enarf_prepare_args *args, enarf_stream_t stre
         if (a.parents[j] < 0 || a.parents[j] >= a.num_joints) return host::fail(ENARF_ERR_ARG, "enarf_prepare: parents[%d]=%d out of range", j, a.parents[j]);
     PrepareParams prm;
     prm.a = a;
-    hipLaunchKernelGGL(prepare_kernel, dim3(a.B), dim3(256), 0, (hipStream_t)stream, prm);
+    hipLaunchKernelGGL(prepare_kernel, dim3(3, a.B), dim3(256), 0, (hipStream_t)stream, prm);
     return host::check_launch("enarf_prepare");
 }
 
