@@ -1,17 +1,18 @@
 #!/bin/bash
-mkdir -p gpurun_out/pmc3
+# profile evidence for profiles/: kernel-trace stats, then PMC groups in separate passes (never combined with sys/hip traces)
+mkdir -p gpurun_out/pmc_final
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/pmc_final
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline > $O/stats.log 2>&1
 run() { n=$1; shift
-  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $R/gpurun_out/pmc3/$n -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline > $R/gpurun_out/pmc3/$n.log 2>&1
+  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/$n -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline > $O/$n.log 2>&1
 }
 run sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD
-run sq2 SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_MISC SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_SCA
-run sq3 SQ_WAIT_INST_LDS SQ_INSTS_VMEM_WR SQ_LDS_IDX_ACTIVE SQ_INSTS_SMEM SQ_INSTS_FLAT SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS
+run sq2 SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VMEM_WR
 run tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TA_TA_BUSY_sum
 run tcc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_REQ_sum
 run fetch FETCH_SIZE
 run write WRITE_SIZE
 run grbm GRBM_GUI_ACTIVE GRBM_COUNT
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/pmc3/stats -- python3 $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline > $R/gpurun_out/pmc3/stats.log 2>&1
-ls $R/gpurun_out/pmc3
+ls $O
