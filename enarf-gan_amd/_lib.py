@@ -63,6 +63,30 @@ class RenderArgs(C.Structure):
     ]
 
 
+class RenderBwdArgs(C.Structure):
+    _fields_ = [
+        ("B", C.c_int), ("n", C.c_int), ("P", C.c_int), ("Nf", C.c_int), ("H", C.c_int), ("W", C.c_int),
+        ("drop_invalid_rays", C.c_int), ("render_scale", C.c_float),
+        ("image_coord", _f32p), ("inv_intrinsics", _f32p), ("parts", _f32p), ("canonical_pose", _f32p),
+        ("feat_cl", _f32p), ("feat_batch_stride", C.c_longlong),
+        ("mask_planes", _f32p), ("mask_batch_stride", C.c_longlong),
+        ("mlp_pack", _f32p), ("bins", _f32p),
+        ("g_color", _f32p), ("g_mask", _f32p), ("g_disparity", _f32p),
+        ("grad_feat_cl", _f32p), ("grad_feat_batch_stride", C.c_longlong),
+        ("grad_mask_planes", _f32p), ("grad_mask_batch_stride", C.c_longlong),
+        ("rows_x", _f32p), ("rows_h1", _f32p), ("rows_h2", _f32p), ("rows_dz1", _f32p), ("rows_dz2", _f32p),
+        ("rows_dz3", _f32p), ("rows_per_image", C.c_longlong), ("row_blocks", _f32p), ("workspace", _f32p),
+    ]
+
+
+class PrepareBwdArgs(C.Structure):
+    _fields_ = [
+        ("B", C.c_int), ("style_dim", C.c_int), ("z_rend", _f32p),
+        ("conv_weight", _f32p * 3), ("mod_weight", _f32p * 3), ("mod_bias", _f32p * 3), ("dW", _f32p * 3),
+        ("d_conv_weight", _f32p * 3), ("d_mod_weight", _f32p * 3), ("d_mod_bias", _f32p * 3), ("d_z_rend", _f32p),
+    ]
+
+
 # every symbol include/enarf_hip.h declares: name -> (restype, argtypes)
 SIGNATURES = {
     "enarf_abi_version": (C.c_int, []),
@@ -79,6 +103,10 @@ SIGNATURES = {
     "enarf_query_fwd": (C.c_int, [C.POINTER(QueryArgs), C.c_void_p]),
     "enarf_render_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "enarf_render_fwd": (C.c_int, [C.POINTER(RenderArgs), C.c_void_p]),
+    "enarf_render_bwd_rows_per_image": (C.c_longlong, [C.c_int, C.c_int]),
+    "enarf_render_bwd": (C.c_int, [C.POINTER(RenderBwdArgs), C.c_void_p]),
+    "enarf_prepare_bwd": (C.c_int, [C.POINTER(PrepareBwdArgs), C.c_void_p]),
+    "enarf_triplane_unpack_add": (C.c_int, [_f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
 }
 
 _lib: Optional[C.CDLL] = None

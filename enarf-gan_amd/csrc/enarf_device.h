@@ -45,7 +45,17 @@ constexpr int PKH_W2 = PKH_W1 + 4 * 2 * 64 * 8;         // [4 ob][2 ks][hi,lo][6
 constexpr int PKH_W3 = PKH_W2 + 4 * 2 * 2 * 64 * 8;     // [2 ks][hi,lo][64][8]
 constexpr int PKH_SHORTS = PKH_W3 + 2 * 2 * 64 * 8;     // 14336 shorts = 28672 B
 // fp16 section: same layout as the bf16 section, hi = f16(w), lo = f16(w - hi)
-constexpr size_t kPackBytes = (size_t)PK_F32_FLOATS * 4 + (size_t)PKH_SHORTS * 2 * 2;   // 86592 B
+// transposed fp32 section (floats, after the fp16 section): A operands of the backward products dH = W^T dZ, same
+// chaining trick (the k-step (ob', r') of a product reads the lane's own register r' of block ob' of dZ):
+//   W3T [4 ob][64 lanes]       : A[i][k] = W3[k][16ob + i]                         (k = the 4 outputs: one K=4 step)
+//   W2T [4 ob][16 q][64 lanes] : A[i][g] = W2[16ob' + 4g + r'][16ob + i]
+//   W1T [2 ob][16 q][64 lanes] : A[i][g] = W1[16ob' + 4g + r'][8(i>>2) + 4ob + (i&3)]   (rows land as channel 8g + 4ob + r)
+constexpr int PKT_W3T = 0;
+constexpr int PKT_W2T = PKT_W3T + 4 * 64;
+constexpr int PKT_W1T = PKT_W2T + 4 * 16 * 64;
+constexpr int PKT_FLOATS = PKT_W1T + 2 * 16 * 64;      // 6400 floats
+constexpr size_t kPackTOff = (size_t)PK_F32_FLOATS * 4 + (size_t)PKH_SHORTS * 2 * 2;    // byte offset of the transposed section
+constexpr size_t kPackBytes = kPackTOff + (size_t)PKT_FLOATS * 4;   // 112192 B
 static_assert(kPackBytes % 16 == 0, "pack must stay 16-byte aligned per image");
 
 // ---- wave primitives ----------------------------------------------------------------------------

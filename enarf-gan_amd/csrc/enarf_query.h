@@ -113,6 +113,77 @@ __device__ __forceinline__ f32x4 mlp_tile_f32(const float *__restrict__ Wp, cons
     return act4(o);       // lanes with g == 0 hold (r, g, b, sigma) pre-activation-head of point j
 }
 
+// ---- fp32 MLP with the activations kept, and its backward (enarf_render_bwd) ---------------------------------------
+// forward: a1, a2 = post-activation hidden layers (lane (j, g) holds units 16ob + 4g + r of point j), o = head
+__device__ __forceinline__ void mlp_tile_f32_keep(const float *__restrict__ Wp, const float *__restrict__ Bp,
+                                                  const float x[8], int lane, f32x4 a1[4], f32x4 a2[4], f32x4 &o) {
+    const int g = lane >> 4;
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) a1[ob] = *reinterpret_cast<const f32x4 *>(Bp + 16 * ob + 4 * g);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob)
+            a1[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wp[PK_W1 + (ob * 8 + s) * 64 + lane], x[s], a1[ob], 0, 0, 0);
+    }
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) {
+        a1[ob] = act4(a1[ob]);
+        a2[ob] = *reinterpret_cast<const f32x4 *>(Bp + 64 + 16 * ob + 4 * g);
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const float bq = a1[q >> 2][q & 3];
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob)
+            a2[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wp[PK_W2 + (ob * 16 + q) * 64 + lane], bq, a2[ob], 0, 0, 0);
+    }
+    o = *reinterpret_cast<const f32x4 *>(Bp + 128 + 4 * g);
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) a2[ob] = act4(a2[ob]);
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+        o = __builtin_amdgcn_mfma_f32_16x16x4f32(Wp[PK_W3 + q * 64 + lane], a2[q >> 2][q & 3], o, 0, 0, 0);
+    o = act4(o);
+}
+// d act / d pre-activation from the post-activation value (act is monotone through 0; torch's leaky_relu uses the
+// negative slope at exactly 0)
+__device__ __forceinline__ float styled_act_grad(float a) { return (a > 0.0f ? 1.0f : 0.2f) * 1.41421356237309515f; }
+
+// backward: dz3v = dL/dz3[unit g][point j] of this lane (lane = 16g + j); returns dz2, dz1 (accumulator layout) and
+// dx[8] = dL/d feature channels 8g..8g+7 of point j.  Wt = transposed section of the pack (LDS).
+__device__ __forceinline__ void mlp_bwd_tile_f32(const float *__restrict__ Wt, const f32x4 a1[4], const f32x4 a2[4],
+                                                 float dz3v, int lane, f32x4 dz2[4], f32x4 dz1[4], float dx[8]) {
+    const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) {
+        dz2[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wt[PKT_W3T + ob * 64 + lane], dz3v, zero, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dz2[ob][r] *= styled_act_grad(a2[ob][r]);
+        dz1[ob] = zero;
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const float bq = dz2[q >> 2][q & 3];
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob)
+            dz1[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wt[PKT_W2T + (ob * 16 + q) * 64 + lane], bq, dz1[ob], 0, 0, 0);
+    }
+    f32x4 d0 = zero, d1 = zero;
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dz1[ob][r] *= styled_act_grad(a1[ob][r]);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const float bq = dz1[q >> 2][q & 3];
+        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(Wt[PKT_W1T + (0 * 16 + q) * 64 + lane], bq, d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(Wt[PKT_W1T + (1 * 16 + q) * 64 + lane], bq, d1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { dx[r] = d0[r]; dx[4 + r] = d1[r]; }
+}
+
 // split-bf16 (NTERMS = 3: hi*hi + hi*lo + lo*hi, ~2^-16 relative) or plain bf16 (NTERMS = 1) on
 // v_mfma_f32_16x16x32_bf16: 14 (x3) MFMAs per tile
 __device__ __forceinline__ void split8(const float v[8], bf16x8 &hi, bf16x8 &lo) {

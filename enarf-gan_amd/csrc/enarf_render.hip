@@ -1,6 +1,6 @@
 // enarf_render.hip - prepare, point-cloud query and the fused ray-march kernels + their C-ABI entry points.
 // gfx950 only. See include/enarf_hip.h for the contract and DESIGN.md for the kernel design.
-#include "enarf_query.h"
+#include "enarf_march.h"
 #include "enarf_host.h"
 #include <cstdlib>
 
@@ -30,6 +30,13 @@ __device__ __forceinline__ void pack_weight_row(float *__restrict__ pf, short *_
                                                 int c, float w) {
     // see the layout comment in enarf_device.h
     const int ob = o >> 4, i = o & 15;
+    {   // transposed section (backward): element W_layer[o][c]
+        float *pt = reinterpret_cast<float *>(reinterpret_cast<char *>(pf) + kPackTOff);
+        const int qo = (o >> 4) * 4 + (o & 3), go = (o & 15) >> 2;          // o as a contraction index 16ob' + 4g + r'
+        if (layer == 2) pt[PKT_W3T + (c >> 4) * 64 + o * 16 + (c & 15)] = w;                    // o < 4 is the k index
+        else if (layer == 1) pt[PKT_W2T + ((c >> 4) * 16 + qo) * 64 + go * 16 + (c & 15)] = w;
+        else pt[PKT_W1T + (((c >> 2) & 1) * 16 + qo) * 64 + go * 16 + (((c >> 3) << 2) | (c & 3))] = w;
+    }
     if (layer == 0) {
         const int g = c >> 3, s = c & 7;
         pf[PK_W1 + (ob * 8 + s) * 64 + g * 16 + i] = w;
@@ -140,62 +147,6 @@ __global__ void mlp_unpack_kernel(const float *__restrict__ pf, float *__restric
         const int e = tid - (64 * 32 + 64 * 64 + 4 * 64);
         dense[tid] = (e < 64) ? pf[PK_B1 + e] : (e < 128) ? pf[PK_B2 + e - 64] : pf[PK_B3 + e - 128];
     }
-}
-
-// =================================================================================================
-// LDS staging shared by the query and render kernels
-// =================================================================================================
-// dynamic LDS layout (floats): [mlp section][bias 144][parts P*20][canon P*12][scratch kScratchFloats]
-constexpr int kScratchFloats = 1024;
-template <int MODE>
-__host__ __device__ constexpr int lds_mlp_floats() {
-    return (MODE == ENARF_MLP_F32) ? PK_B1 : PKH_SHORTS / 2;
-}
-template <int MODE>
-__host__ __device__ inline int lds_total_floats(int P) {
-    return lds_mlp_floats<MODE>() + 144 + P * kLdsPartStride + P * kLdsCanonStride + kScratchFloats;
-}
-
-template <int MODE>
-__device__ __forceinline__ void stage_common(float *lds, QueryCtx &S, float *&scratch, const void *pack_b,
-                                             const float *parts_b, const float *canon_pose, int P, int tid,
-                                             int nthreads) {
-    float *l_mlp = lds;
-    float *l_bias = l_mlp + lds_mlp_floats<MODE>();
-    float *l_parts = l_bias + 144;
-    float *l_canon = l_parts + P * kLdsPartStride;
-    scratch = l_canon + P * kLdsCanonStride;
-    const float *pf = reinterpret_cast<const float *>(pack_b);
-    const f32x4 *src4 = (MODE == ENARF_MLP_F32) ? reinterpret_cast<const f32x4 *>(pf)
-                        : (MODE == ENARF_MLP_F16X3) ? reinterpret_cast<const f32x4 *>(pf + PK_F32_FLOATS + PKH_SHORTS / 2)
-                                                    : reinterpret_cast<const f32x4 *>(pf + PK_F32_FLOATS);
-    f32x4 *dst4 = reinterpret_cast<f32x4 *>(l_mlp);
-    for (int i = tid; i < lds_mlp_floats<MODE>() / 4; i += nthreads) dst4[i] = src4[i];
-    for (int i = tid; i < 144; i += nthreads) l_bias[i] = pf[PK_B1 + i];
-    for (int i = tid; i < P * kPartStride; i += nthreads)
-        l_parts[(i / kPartStride) * kLdsPartStride + (i % kPartStride)] = parts_b[i];
-    for (int i = tid; i < P * 12; i += nthreads) {   // (P,4,4) -> Rc row-major 9 + tc 3
-        const int k = i / 12, e = i % 12;
-        l_canon[i] = (e < 9) ? canon_pose[k * 16 + (e / 3) * 4 + (e % 3)] : canon_pose[k * 16 + (e - 9) * 4 + 3];
-    }
-    S.mlp = l_mlp;
-    S.mlp_h = reinterpret_cast<const short *>(l_mlp);
-    S.bias = l_bias;
-    S.parts = l_parts;
-    S.canon = l_canon;
-}
-
-// head: tanh colour, MyReLU * 10 density, density *= any_valid   (triplane_nerf.py:44-47, narf.py:271-274, :204)
-__device__ __forceinline__ float density_head(float sigma_act, uint32_t bits, float wmax, int mult_w, int P) {
-    float d = fmaxf(sigma_act, 0.0f);
-    if (mult_w) {
-        // max over ALL parts of the weight tensor; invalid parts sit at sigmoid(0)^3 = 0.125
-        const float wm = (__popc(bits) < P) ? fmaxf(wmax, 0.125f) : wmax;
-        d = d * (10.0f * wm);
-    } else {
-        d = d * 10.0f;
-    }
-    return bits ? d : 0.0f;
 }
 
 // =================================================================================================
@@ -311,21 +262,11 @@ __device__ __forceinline__ bool ray_hits_part(const float *F, float dx, float dy
     return t0 <= t1;
 }
 
-// wave-private compaction of a part bit set into an LDS list; returns the count
-__device__ __forceinline__ int build_cand_list(int *list, uint32_t set, int lane) {
-    if (lane < 32 && ((set >> lane) & 1u)) list[__popc(set & ((1u << lane) - 1u))] = lane;
-    return __popc(set);
-}
-
 // =================================================================================================
 // ray set-up pre-pass: depth range, candidate parts and the compacted list of rays to march
 // =================================================================================================
 // workspace layout: 64-byte header: [0] unused, [1] number of live rays, [2..9] the 8 per-XCD queue heads (u32); then one 16-byte record
 // per ray {depth_min, depth_max, candidate part bits, valid}; then the list of live ray ids (u32).
-struct RayRec { float dmin, dmax; uint32_t cand, valid; };
-__host__ __device__ inline size_t ws_records_off() { return 64; }
-__host__ __device__ inline size_t ws_list_off(long long total_rays) { return 64 + (size_t)total_rays * sizeof(RayRec); }
-
 // decide_frustrum_range (rendering.py:10-79) for every ray, 4 adjacent lanes per ray: the quad splits the parts
 // for the conservative slab tests and the 32 range-test depths (8 each) for the exact cube tests. Rays the
 // reference drops (batch 1, no cube hit: rendering.py:107-110, :337-350) get their zero outputs here and never
@@ -422,7 +363,7 @@ __global__ __launch_bounds__(256) void ray_setup_kernel(const enarf_render_args 
             a.dbg_ray_valid[rid] = ray_valid ? 1 : 0;
         }
     }
-    if (in_range && !live) {   // dropped ray: zeros (rendering.py:337-350)
+    if (in_range && !live && a.color) {   // dropped ray: zeros (rendering.py:337-350); the backward passes no outputs
         if (g < 3) a.color[((size_t)b * 3 + g) * n + ray] = 0.0f;
         if (g == 3) { a.mask[rid] = 0.0f; a.disparity[rid] = 0.0f; }
         if (a.fine_weights) for (int i = g; i < Nf - 1; i += 4) a.fine_weights[rid * (Nf - 1) + i] = 0.0f;
@@ -443,21 +384,6 @@ __global__ __launch_bounds__(256) void ray_setup_kernel(const enarf_render_args 
         uint32_t *list = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(a.workspace) + ws_list_off((long long)a.B * n));
         list[pos] = (uint32_t)rid;
     }
-}
-
-// ---- XCD-affine ray queues ---------------------------------------------------------------------------------------
-// The live-ray list is cut into blocks of kQBlock consecutive entries that are dealt round-robin to 8 queues, one
-// per XCD; a workgroup pulls from the queue of the XCD it runs on (HW_REG_XCC_ID). Neighbouring rays - which touch
-// neighbouring tri-plane texels - are then marched on ONE XCD and share its L2, instead of every XCD pulling the
-// whole window's footprint through its own L2. Placement only affects speed: any workgroup may serve any queue.
-constexpr int kQBlock = 32;
-constexpr int kQueues = 8;
-__device__ __forceinline__ int xcc_id() {
-    return (int)(__builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11)) & 0xF);   // HW_REG_XCC_ID[3:0]
-}
-// j-th dequeue of queue x -> index into the live list (may be >= total: then the queue is drained)
-__device__ __forceinline__ long long queue_entry(unsigned int j, int x) {
-    return ((long long)(j / kQBlock) * kQueues + x) * kQBlock + (j % kQBlock);
 }
 
 // scratch layout (floats) of the render kernel
@@ -761,18 +687,33 @@ extern "C" int enarf_query_fwd(const enarf_query_args *args, enarf_stream_t stre
     }
 }
 
-template <int MODE>
-static int launch_render(const enarf_render_args &a, hipStream_t st) {
-    // persistent grid: as many workgroups as stay resident (3 per CU at <= 168 VGPRs and ~37 KB LDS), never more
-    // than there are rays
+namespace enarf {
+// zero the workspace header and run the ray set-up pre-pass (also used by the backward)
+int launch_ray_setup(const enarf_render_args &a, hipStream_t st) {
+    hipError_t e = hipMemsetAsync(a.workspace, 0, 64, st);
+    if (e != hipSuccess) return host::fail((int)e, "ray set-up: hipMemsetAsync(workspace) failed: %s", hipGetErrorString(e));
+    const int bpi = (a.n + 63) / 64;
+    hipLaunchKernelGGL(ray_setup_kernel, dim3((unsigned)(bpi * a.B)), dim3(256), 0, st, a, bpi);
+    return host::check_launch("ray set-up");
+}
+int device_cus() {
     static int num_cus = 0;
     if (num_cus == 0) {
         int dev = 0;
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
-            return host::fail((int)hipGetLastError(), "enarf_render_fwd: cannot query the device");
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
         num_cus = prop.multiProcessorCount;
     }
+    return num_cus;
+}
+}  // namespace enarf
+
+template <int MODE>
+static int launch_render(const enarf_render_args &a, hipStream_t st) {
+    // persistent grid: as many workgroups as stay resident (3 per CU at <= 168 VGPRs and ~37 KB LDS), never more
+    // than there are rays
+    const int num_cus = device_cus();
+    if (num_cus <= 0) return host::fail((int)hipGetLastError(), "enarf_render_fwd: cannot query the device");
     const long long total = (long long)a.B * a.n;
     const char *wp = getenv("ENARF_WGS_PER_CU");      // tuning only
     const int per_cu = (wp && atoi(wp) > 0) ? atoi(wp) : ENARF_RENDER_WAVES_PER_SIMD;
@@ -780,11 +721,7 @@ static int launch_render(const enarf_render_args &a, hipStream_t st) {
     if (wgs > total) wgs = total;
     const size_t lds = (size_t)lds_total_floats<MODE>(a.P) * 4;
     const char *ab = getenv("ENARF_ABLATE");      // diagnosis only: 1 skip feature gathers, 2 skip mask planes, 4 skip MLP
-    hipError_t e = hipMemsetAsync(a.workspace, 0, 64, st);
-    if (e != hipSuccess) return host::fail((int)e, "enarf_render_fwd: hipMemsetAsync(workspace) failed: %s", hipGetErrorString(e));
-    const int bpi = (a.n + 63) / 64;
-    hipLaunchKernelGGL(ray_setup_kernel, dim3((unsigned)(bpi * a.B)), dim3(256), 0, st, a, bpi);
-    if (int rc = host::check_launch("enarf_render_fwd(ray set-up)")) return rc;
+    if (int rc = launch_ray_setup(a, st)) return rc;
     hipLaunchKernelGGL(render_kernel<MODE>, dim3((unsigned)wgs), dim3(256), lds, st, a, ab ? atoi(ab) : 0);
     return host::check_launch("enarf_render_fwd");
 }

@@ -1,0 +1,457 @@
+// enarf_render_bwd.hip - backward of the fused renderer. gfx950 only.
+//
+// What the reference's autograd computes through render (rendering.py:283-335), the fine-pass query
+// (models/narf.py:176-275), StyledMLP (libraries/NeRF/net.py:10-27) and MyReLU (libraries/NeRF/activation.py:5-16):
+// gradients w.r.t. the tri-plane and (through per-tile rows + a library GEMM + enarf_prepare_bwd) the MLP parameters
+// and z_rend. Only the fine pass carries gradient (the importance samples are drawn without it) and poses none.
+//
+// One workgroup (4 waves) per ray, as in the forward:
+//   F1  each wave recomputes its 16 fine samples (gather rounds + fp32 MLP, activations kept in registers)
+//   F2  wave 0, lane = sample: compositing backward (prefix / suffix sums) -> dL/dz3 of every sample, via LDS
+//   F3  each wave: MLP backward on MFMA (transposed weights, same accumulator-as-operand chaining), rows out
+//   F4  each wave: second pass over its (sample, part) pairs: scatter d feature / d part-probability into the
+//       gradient planes with float atomics
+#include "enarf_march.h"
+#include "enarf_host.h"
+#include <cstdlib>
+
+namespace enarf {
+
+constexpr int kBwdWavesPerSimd = 2;
+
+// LDS scratch of the backward kernel (floats)
+constexpr int SB_CAND = 0;        // 4 waves x 32 ints
+constexpr int SB_FH = 128;        // head [4][64]
+constexpr int SB_FBITS = 384;     // bits [64]
+constexpr int SB_DZ3 = 448;       // dL/dz3 [4][64]
+constexpr int SB_QUEUE = 704;     // 2 ray ids
+static_assert(SB_QUEUE + 2 <= kScratchFloats, "scratch overflow");
+
+__host__ __device__ inline int bwd_lds_floats(int P) {
+    return PK_B1 + 144 + PKT_FLOATS + P * kLdsPartStride + P * kLdsCanonStride + kScratchFloats;
+}
+
+// d loss / d the 4 texels of one plane, this lane's 8 channels: grad[texel][c] += bilinear weight * w_k * dx[c]
+__device__ __forceinline__ void scatter_tap(float *__restrict__ dst, float cf, const float dxg[8]) {
+    if (cf != 0.0f) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) atomicAdd(dst + c, cf * dxg[c]);
+    }
+}
+__device__ __forceinline__ void scatter_plane(float *__restrict__ gpl, const Taps &t, float wk, const float dxg[8]) {
+    scatter_tap(gpl + (size_t)t.o00 * kFeat, t.w00 * wk, dxg);
+    scatter_tap(gpl + (size_t)t.o01 * kFeat, t.w01 * wk, dxg);
+    scatter_tap(gpl + (size_t)t.o10 * kFeat, t.w10 * wk, dxg);
+    scatter_tap(gpl + (size_t)t.o11 * kFeat, t.w11 * wk, dxg);
+}
+
+__global__ __launch_bounds__(256, kBwdWavesPerSimd) void render_bwd_kernel(const enarf_render_bwd_args a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int P = a.P, Nf = a.Nf, n = a.n;
+    unsigned int *wsh = reinterpret_cast<unsigned int *>(a.workspace);
+    const long long total_live = (long long)wsh[1];
+    const int my_q = xcc_id() & (kQueues - 1);
+    unsigned int *queue = wsh + 2 + my_q;
+    const RayRec *recs = reinterpret_cast<const RayRec *>(reinterpret_cast<const char *>(a.workspace) + ws_records_off());
+    const uint32_t *live_list = reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(a.workspace) +
+                                                                  ws_list_off((long long)a.B * n));
+    // LDS: [fp32 weights PK_B1][bias 144][transposed PKT_FLOATS][parts][canon][scratch]
+    float *l_w = lds, *l_bias = l_w + PK_B1, *l_wt = l_bias + 144, *l_parts = l_wt + PKT_FLOATS;
+    float *l_canon = l_parts + P * kLdsPartStride, *scratch = l_canon + P * kLdsCanonStride;
+    int *l_q = reinterpret_cast<int *>(scratch + SB_QUEUE);
+    if (tid == 0) l_q[0] = (int)atomicAdd(queue, 1u);
+    __syncthreads();
+    long long cur = queue_entry((unsigned int)l_q[0], my_q);
+    if (cur >= total_live) return;
+    int b = -1;
+    QueryCtx S;
+    S.mlp = l_w; S.mlp_h = nullptr; S.bias = l_bias; S.parts = l_parts; S.canon = l_canon;
+    S.H = a.H; S.W = a.W; S.P = P; S.mult_w = 0; S.ablate = 0;
+    int *l_cand = reinterpret_cast<int *>(scratch + SB_CAND) + wave * 32;
+    float *l_fh = scratch + SB_FH, *l_dz3 = scratch + SB_DZ3;
+    uint32_t *l_fbits = reinterpret_cast<uint32_t *>(scratch + SB_FBITS);
+    const int Tf = (Nf + 3) >> 2;
+    const int j4 = lane >> 2, g4 = lane & 3;
+    const size_t mplane = (size_t)a.H * a.W, fplane = mplane * kFeat;
+    int qslot = 0;
+    float *gfeat = nullptr, *gmask = nullptr;
+
+    while (cur < total_live) {
+        if (tid == 0) l_q[qslot ^ 1] = (int)atomicAdd(queue, 1u);
+        const uint32_t rid = live_list[cur];
+        const int nb = (int)(rid / (uint32_t)n), ray = (int)(rid - (uint32_t)nb * (uint32_t)n);
+        if (nb != b) {   // (re)stage the image's weights (forward + transposed), biases and frames
+            if (b >= 0) __syncthreads();
+            b = nb;
+            const float *pf = reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.mlp_pack) + (size_t)b * kPackBytes);
+            const float *pt = reinterpret_cast<const float *>(reinterpret_cast<const char *>(pf) + kPackTOff);
+            for (int i = tid; i < PK_B1 / 4; i += 256) reinterpret_cast<f32x4 *>(l_w)[i] = reinterpret_cast<const f32x4 *>(pf)[i];
+            for (int i = tid; i < 144; i += 256) l_bias[i] = pf[PK_B1 + i];
+            for (int i = tid; i < PKT_FLOATS / 4; i += 256) reinterpret_cast<f32x4 *>(l_wt)[i] = reinterpret_cast<const f32x4 *>(pt)[i];
+            const float *parts_b = a.parts + (size_t)b * P * kPartStride;
+            for (int i = tid; i < P * kPartStride; i += 256)
+                l_parts[(i / kPartStride) * kLdsPartStride + (i % kPartStride)] = parts_b[i];
+            for (int i = tid; i < P * 12; i += 256) {
+                const int k = i / 12, e = i % 12;
+                l_canon[i] = (e < 9) ? a.canonical_pose[k * 16 + (e / 3) * 4 + (e % 3)] : a.canonical_pose[k * 16 + (e - 9) * 4 + 3];
+            }
+            S.feat = a.feat_cl + (size_t)b * a.feat_batch_stride;
+            S.mask = a.mask_planes + (size_t)b * a.mask_batch_stride;
+            gfeat = a.grad_feat_cl + (size_t)b * a.grad_feat_batch_stride;
+            gmask = a.grad_mask_planes + (size_t)b * a.grad_mask_batch_stride;
+            __syncthreads();
+        }
+        const float *coord = a.image_coord + (size_t)b * 3 * n;
+        const float *Ki = a.inv_intrinsics + (size_t)b * 9;
+        const float u = coord[ray], v = coord[n + ray], w = coord[2 * n + ray];
+        const float dx_ = exact_dot3(Ki[0], u, Ki[1], v, Ki[2], w);
+        const float dy_ = exact_dot3(Ki[3], u, Ki[4], v, Ki[5], w);
+        const float dz_ = exact_dot3(Ki[6], u, Ki[7], v, Ki[8], w);
+        const RayRec rec = recs[rid];
+        const float dmin = rec.dmin, dmax = rec.dmax;
+        const int ncand = build_cand_list(l_cand, rec.cand, lane);
+        const float sx = exact_mul(dmin, dx_), sy = exact_mul(dmin, dy_), sz = exact_mul(dmin, dz_);
+        const float ex = exact_mul(dmax, dx_), ey = exact_mul(dmax, dy_), ez = exact_mul(dmax, dz_);
+        const float *bins = a.bins + ((size_t)b * n + ray) * Nf;
+
+        // ---- F1: forward of this wave's fine samples (gather layout: lane = 4 sample + chunk)
+        const int i = wave * Tf + j4;
+        const bool active = (j4 < Tf) && (i < Nf - 1);
+        const float bi = bins[min(i, Nf - 1)];
+        const float px = exact_lerp(sx, ex, bi), py = exact_lerp(sy, ey, bi), pz = exact_lerp(sz, ez, bi);
+        uint32_t bits;
+        float feat[8];
+        {
+            uint32_t mine = 0;
+            for (int i0 = 0; i0 < ncand; i0 += 4) {
+                const int idx = i0 + g4;
+                const bool has = idx < ncand;
+                const int k = l_cand[has ? idx : 0];
+                float F[13], Cn[12], lx, ly, lz, cx, cy, cz;
+                load_frames(S, k, F, Cn);
+                exact_local(F, px, py, pz, lx, ly, lz);
+                exact_canonical(Cn, F[12], lx, ly, lz, cx, cy, cz);
+                if (active && has && in_unit_cube_incl(lx, ly, lz) && in_unit_cube_strict(cx, cy, cz)) mine |= (1u << k);
+            }
+            bits = mine | (uint32_t)quad_perm_i<0xB1>((int)mine);
+            bits |= (uint32_t)quad_perm_i<0x4E>((int)bits);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) feat[c] = 0.0f;
+            uint32_t rem = bits;
+            while (true) {
+                const uint64_t bal = __ballot(rem != 0);
+                if (bal == 0) break;
+                const bool act = rem != 0;
+                const int k = act ? __builtin_ctz(rem) : 0;
+                rem &= rem - 1;
+                float F[13], Cn[12], lx, ly, lz, cx, cy, cz;
+                load_frames(S, k, F, Cn);
+                exact_local(F, px, py, pz, lx, ly, lz);
+                exact_canonical(Cn, F[12], lx, ly, lz, cx, cy, cz);
+                const float qx = (g4 == 1) ? cy : (g4 == 2) ? cz : cx;
+                const float qy = (g4 == 1) ? cz : (g4 == 2) ? cx : cy;
+                const Taps t = make_taps(qx, qy, a.H, a.W);
+                float sg = 1.0f;
+                if (act && g4 < 3) {
+                    const float *mp = S.mask + (size_t)(3 * k + g4) * mplane;
+                    float acc = mp[t.o00] * t.w00;
+                    acc += mp[t.o01] * t.w01;
+                    acc += mp[t.o10] * t.w10;
+                    acc += mp[t.o11] * t.w11;
+                    sg = sigmoidf_(acc);
+                }
+                const float wk = (quad_bcast_f<0>(sg) * quad_bcast_f<1>(sg)) * quad_bcast_f<2>(sg);
+                const Taps t0 = quad_bcast_taps<0>(t), t1 = quad_bcast_taps<1>(t), t2 = quad_bcast_taps<2>(t);
+                if (act) {
+                    float s0[8], s1[8], s2[8];
+                    const float *featg = S.feat + 8 * g4;
+                    tap4(featg, t0, s0);
+                    tap4(featg + fplane, t1, s1);
+                    tap4(featg + 2 * fplane, t2, s2);
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) feat[c] += ((s0[c] + s1[c]) + s2[c]) * wk;
+                }
+            }
+        }
+        const bool ran = __ballot(bits != 0) != 0;      // wave-uniform
+        f32x4 a1[4], a2[4], o;
+        float x[8];
+        if (ran) {
+            const int src = ((lane & 15) << 2) | (lane >> 4);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) x[c] = __shfl(feat[c], src);
+            mlp_tile_f32_keep(l_w, l_bias, x, lane, a1, a2, o);
+        } else {
+            o = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+        if (lane < Tf && wave * Tf + lane < Nf) {
+            const int io = wave * Tf + lane;
+            l_fh[io] = o[0]; l_fh[64 + io] = o[1]; l_fh[128 + io] = o[2]; l_fh[192 + io] = o[3];
+        }
+        if ((j4 < Tf) && (i < Nf) && g4 == 0) l_fbits[i] = active ? bits : 0u;
+        __syncthreads();
+        const long long next_ray = queue_entry((unsigned int)l_q[qslot ^ 1], my_q);
+        qslot ^= 1;
+
+        // ---- F2 (wave 0, lane = sample): compositing backward -> dL/dz3
+        if (wave == 0) {
+            const size_t ro = (size_t)b * n + ray;
+            const float gC0 = a.g_color ? a.g_color[((size_t)b * 3 + 0) * n + ray] : 0.0f;
+            const float gC1 = a.g_color ? a.g_color[((size_t)b * 3 + 1) * n + ray] : 0.0f;
+            const float gC2 = a.g_color ? a.g_color[((size_t)b * 3 + 2) * n + ray] : 0.0f;
+            const float gM = a.g_mask ? a.g_mask[ro] : 0.0f;
+            const float gD = a.g_disparity ? a.g_disparity[ro] : 0.0f;
+            const int ci = min(lane, Nf - 1);
+            const bool seg = lane < Nf - 1;
+            const uint32_t sb = l_fbits[ci];
+            const float h0 = l_fh[ci], h1 = l_fh[64 + ci], h2 = l_fh[128 + ci], h3 = l_fh[192 + ci];
+            const float den = seg ? density_head(h3, sb, 0.0f, 0, P) : 0.0f;
+            const float cr = tanhf(h0), cg = tanhf(h1), cb = tanhf(h2);
+            const float fdepth = exact_lerp(dmin, dmax, bins[ci]);
+            const float delta = __shfl_down(fdepth, 1) - fdepth;
+            const float aa = seg ? den * delta * a.render_scale : 0.0f;
+            const float cs = wave_scan_incl(aa, lane);
+            const float T = expf(-(cs - aa)), ea = expf(-aa);
+            const float wgt = seg ? T * (1.0f - ea) : 0.0f;
+            const float G = seg ? (gC0 * cr + gC1 * cg + gC2 * cb) + gM + gD / fdepth : 0.0f;
+            const float gw = G * wgt;
+            const float incl = wave_scan_incl(gw, lane);
+            const float suffix = __shfl(incl, 63) - incl;                     // sum_{j>i} G_j w_j
+            const float d_a = G * T * ea - suffix;                            // dL/d(sigma delta)
+            const float d_sigma = seg ? d_a * delta * a.render_scale : 0.0f;
+            // density = MyReLU(h3) * 10 * any_valid; MyReLU backward: slope 0.1 for x < 0 when the gradient is negative
+            const float gy = sb ? d_sigma * 10.0f : 0.0f;
+            const float gx = (h3 >= 0.0f) ? gy : ((gy < 0.0f) ? 0.1f * gy : 0.0f);
+            l_dz3[192 + lane] = seg ? gx * styled_act_grad(h3) : 0.0f;
+            l_dz3[lane] = seg ? (1.0f - cr * cr) * (wgt * gC0) * styled_act_grad(h0) : 0.0f;
+            l_dz3[64 + lane] = seg ? (1.0f - cg * cg) * (wgt * gC1) * styled_act_grad(h1) : 0.0f;
+            l_dz3[128 + lane] = seg ? (1.0f - cb * cb) * (wgt * gC2) * styled_act_grad(h2) : 0.0f;
+        }
+        __syncthreads();
+
+        // ---- F3 + F4: MLP backward and scatter, per wave (skipped when the tile has no valid sample: then dz3 = 0)
+        if (ran) {
+            const int mj = lane & 15, mg = lane >> 4;          // MFMA layout: point mj, k-group mg
+            const int ms = min(wave * Tf + mj, Nf - 1);
+            const float dz3v = (mj < Tf) ? l_dz3[mg * 64 + ms] : 0.0f;
+            f32x4 dz2[4], dz1[4];
+            float dxm[8];
+            mlp_bwd_tile_f32(l_wt, a1, a2, dz3v, lane, dz2, dz1, dxm);
+            // rows for the weight gradients: block of 16 rows of image b
+            unsigned int blk = 0;
+            if (lane == 0) blk = atomicAdd(a.row_blocks + b, 1u);
+            blk = (unsigned int)__builtin_amdgcn_readfirstlane((int)blk);
+            const size_t row = (size_t)b * a.rows_per_image + (size_t)blk * 16 + mj;
+            {
+                f32x4 *rx = reinterpret_cast<f32x4 *>(a.rows_x + row * 32 + 8 * mg);
+                rx[0] = f32x4{x[0], x[1], x[2], x[3]};
+                rx[1] = f32x4{x[4], x[5], x[6], x[7]};
+#pragma unroll
+                for (int ob = 0; ob < 4; ++ob) {
+                    *reinterpret_cast<f32x4 *>(a.rows_h1 + row * 64 + 16 * ob + 4 * mg) = a1[ob];
+                    *reinterpret_cast<f32x4 *>(a.rows_h2 + row * 64 + 16 * ob + 4 * mg) = a2[ob];
+                    *reinterpret_cast<f32x4 *>(a.rows_dz1 + row * 64 + 16 * ob + 4 * mg) = dz1[ob];
+                    *reinterpret_cast<f32x4 *>(a.rows_dz2 + row * 64 + 16 * ob + 4 * mg) = dz2[ob];
+                }
+                a.rows_dz3[row * 4 + mg] = dz3v;
+            }
+            // d feature back in the gather layout
+            float dxg[8];
+            const int src2 = (g4 << 4) | j4;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) dxg[c] = __shfl(dxm[c], src2);
+
+            // ---- F4: second pass over the pairs: d part-probability and d feature texels
+            uint32_t rem = bits;
+            while (true) {
+                const uint64_t bal = __ballot(rem != 0);
+                if (bal == 0) break;
+                const bool act = rem != 0;
+                const int k = act ? __builtin_ctz(rem) : 0;
+                rem &= rem - 1;
+                float F[13], Cn[12], lx, ly, lz, cx, cy, cz;
+                load_frames(S, k, F, Cn);
+                exact_local(F, px, py, pz, lx, ly, lz);
+                exact_canonical(Cn, F[12], lx, ly, lz, cx, cy, cz);
+                const float qx = (g4 == 1) ? cy : (g4 == 2) ? cz : cx;
+                const float qy = (g4 == 1) ? cz : (g4 == 2) ? cx : cy;
+                const Taps t = make_taps(qx, qy, a.H, a.W);
+                float sg = 1.0f;
+                if (act && g4 < 3) {
+                    const float *mp = S.mask + (size_t)(3 * k + g4) * mplane;
+                    float acc = mp[t.o00] * t.w00;
+                    acc += mp[t.o01] * t.w01;
+                    acc += mp[t.o10] * t.w10;
+                    acc += mp[t.o11] * t.w11;
+                    sg = sigmoidf_(acc);
+                }
+                const float wk = (quad_bcast_f<0>(sg) * quad_bcast_f<1>(sg)) * quad_bcast_f<2>(sg);
+                const Taps t0 = quad_bcast_taps<0>(t), t1 = quad_bcast_taps<1>(t), t2 = quad_bcast_taps<2>(t);
+                float dot = 0.0f;
+                if (act) {
+                    float s0[8], s1[8], s2[8];
+                    const float *featg = S.feat + 8 * g4;
+                    tap4(featg, t0, s0);
+                    tap4(featg + fplane, t1, s1);
+                    tap4(featg + 2 * fplane, t2, s2);
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) dot += dxg[c] * ((s0[c] + s1[c]) + s2[c]);
+                }
+                dot += quad_perm_f<0xB1>(dot);
+                dot += quad_perm_f<0x4E>(dot);                                  // d loss / d w_k, quad-uniform
+                if (act) {
+                    if (g4 < 3) {   // w = s0 s1 s2, s = sigmoid(m): dw/dm_g = w (1 - s_g)
+                        const float gm = dot * wk * (1.0f - sg);
+                        float *gp = gmask + (size_t)(3 * k + g4) * mplane;
+                        if (t.w00 != 0.0f) atomicAdd(gp + t.o00, t.w00 * gm);
+                        if (t.w01 != 0.0f) atomicAdd(gp + t.o01, t.w01 * gm);
+                        if (t.w10 != 0.0f) atomicAdd(gp + t.o10, t.w10 * gm);
+                        if (t.w11 != 0.0f) atomicAdd(gp + t.o11, t.w11 * gm);
+                    }
+                    float *gf = gfeat + 8 * g4;
+                    scatter_plane(gf, t0, wk, dxg);
+                    scatter_plane(gf + fplane, t1, wk, dxg);
+                    scatter_plane(gf + 2 * fplane, t2, wk, dxg);
+                }
+            }
+        }
+        // the next ray's first barrier orders this ray's LDS reads (l_dz3, l_fh) before their next writes
+        __syncthreads();
+        cur = next_ray;
+    }
+}
+
+// ---- grad_tri[:, :96] += channel-last gradient (inverse re-layout) ---------------------------------------------------
+__global__ __launch_bounds__(256) void unpack_add_kernel(const float *__restrict__ cl, float *__restrict__ out,
+                                                         int out_ch_total, int H, int W) {
+    constexpr int C = kFeat;
+    __shared__ float tile[C * 65];
+    const int tid = threadIdx.x;
+    const int xb = blockIdx.x * 64, y = blockIdx.y, bp = blockIdx.z, b = bp / 3, p = bp % 3;
+    const float *src = cl + ((((size_t)b * 3 + p) * H + y) * W + xb) * C;
+    const int nvalid = min(64, W - xb) * C;
+    for (int o = tid; o < nvalid; o += 256) tile[(o % C) * 65 + (o / C)] = src[o];
+    __syncthreads();
+    float *dst = out + (((size_t)b * out_ch_total + p * C) * H + y) * W;
+    const int x = tid & 63;
+    for (int c = tid >> 6; c < C; c += 4)
+        if (xb + x < W) dst[(size_t)c * H * W + xb + x] += tile[c * 65 + x];
+}
+
+// ---- backward of ModulatedConv1d's weight path: dW' -> d conv.weight, d modulation.{weight,bias}, d z_rend ---------------
+// u = (W / sqrt(in)) * s (s broadcast over rows), W' = u / max(||u||_row, 1e-12), s = z Wm^T / sqrt(D) + bm
+__global__ __launch_bounds__(256) void prepare_bwd_kernel(const enarf_prepare_bwd_args a) {
+    const int layer = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int cin = (layer == 0) ? kFeat : kHid, cout = (layer == 2) ? 4 : kHid, D = a.style_dim;
+    __shared__ float s_style[kHid], s_ds[kHid], s_rn[kHid], s_dot[kHid];
+    __shared__ float s_u[kHid * kHid];
+    const float *z = a.z_rend + (size_t)b * D;
+    const float mscale = 1.0f / sqrtf((float)D), cscale = 1.0f / sqrtf((float)cin);
+    if (tid < cin) {
+        const float *wm = a.mod_weight[layer] + (size_t)tid * D;
+        float acc = 0.0f;
+        for (int d = 0; d < D; ++d) acc += z[d] * (wm[d] * mscale);
+        s_style[tid] = acc + a.mod_bias[layer][tid];
+        s_ds[tid] = 0.0f;
+    }
+    __syncthreads();
+    for (int e = tid; e < cout * cin; e += 256) s_u[e] = (cscale * a.conv_weight[layer][e]) * s_style[e % cin];
+    __syncthreads();
+    const float *dW = a.dW[layer] + (size_t)b * cout * cin;
+    if (tid < cout) {   // per row: r = max(||u||, eps); W' = u / r; du = (dW' - W' (W' . dW')) / r
+        float ss = 0.0f;
+        for (int c = 0; c < cin; ++c) ss += s_u[tid * cin + c] * s_u[tid * cin + c];
+        const float r = fmaxf(sqrtf(ss), 1e-12f);
+        float dot = 0.0f;
+        for (int c = 0; c < cin; ++c) dot += (s_u[tid * cin + c] / r) * dW[tid * cin + c];
+        s_rn[tid] = 1.0f / r;
+        s_dot[tid] = dot;
+    }
+    __syncthreads();
+    float *dcw = a.d_conv_weight[layer] + (size_t)b * cout * cin;
+    for (int e = tid; e < cout * cin; e += 256) {
+        const int o = e / cin, c = e % cin;
+        const float du = (dW[e] - (s_u[e] * s_rn[o]) * s_dot[o]) * s_rn[o];
+        dcw[e] = du * cscale * s_style[c];
+        s_u[e] = du * cscale * a.conv_weight[layer][e];          // contribution to ds_c (reuse the buffer)
+    }
+    __syncthreads();
+    if (tid < cin) {
+        float ds = 0.0f;
+        for (int o = 0; o < cout; ++o) ds += s_u[o * cin + tid];
+        s_ds[tid] = ds;
+        a.d_mod_bias[layer][(size_t)b * cin + tid] = ds;
+    }
+    __syncthreads();
+    float *dmw = a.d_mod_weight[layer] + (size_t)b * cin * D;
+    for (int e = tid; e < cin * D; e += 256) dmw[e] = s_ds[e / D] * z[e % D] * mscale;
+    for (int d = tid; d < D; d += 256) {
+        float acc = 0.0f;
+        for (int c = 0; c < cin; ++c) acc += s_ds[c] * a.mod_weight[layer][(size_t)c * D + d];
+        a.d_z_rend[((size_t)b * 3 + layer) * D + d] = acc * mscale;
+    }
+}
+
+}  // namespace enarf
+
+using namespace enarf;
+
+extern "C" long long enarf_render_bwd_rows_per_image(int n, int Nf) {
+    if (n <= 0 || Nf <= 0) return 0;
+    return (long long)n * 64;     // 4 tiles of 16 rows per ray at most
+}
+
+extern "C" int enarf_render_bwd(const enarf_render_bwd_args *args, enarf_stream_t stream) {
+    if (!args) return host::fail(ENARF_ERR_ARG, "enarf_render_bwd: args is null");
+    const enarf_render_bwd_args &a = *args;
+    if (a.B <= 0 || a.n <= 0 || a.P <= 0 || a.P > ENARF_MAX_PARTS || a.H <= 0 || a.W <= 0)
+        return host::fail(ENARF_ERR_ARG, "enarf_render_bwd: bad sizes");
+    if (a.Nf < 2 || a.Nf > 64) return host::fail(ENARF_ERR_UNSUPPORTED, "enarf_render_bwd: Nf=%d outside [2, 64]", a.Nf);
+    if (!a.image_coord || !a.inv_intrinsics || !a.parts || !a.canonical_pose || !a.feat_cl || !a.mask_planes || !a.mlp_pack ||
+        !a.bins || !a.grad_feat_cl || !a.grad_mask_planes || !a.rows_x || !a.rows_h1 || !a.rows_h2 || !a.rows_dz1 ||
+        !a.rows_dz2 || !a.rows_dz3 || !a.row_blocks || !a.workspace)
+        return host::fail(ENARF_ERR_ARG, "enarf_render_bwd: null pointer");
+    if (a.rows_per_image < enarf_render_bwd_rows_per_image(a.n, a.Nf))
+        return host::fail(ENARF_ERR_ARG, "enarf_render_bwd: rows_per_image %lld < %lld", a.rows_per_image,
+                          enarf_render_bwd_rows_per_image(a.n, a.Nf));
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(a.row_blocks, 0, sizeof(unsigned int) * a.B, st);
+    if (e != hipSuccess) return host::fail((int)e, "enarf_render_bwd: hipMemsetAsync failed: %s", hipGetErrorString(e));
+    enarf_render_args f = {};
+    f.B = a.B; f.n = a.n; f.P = a.P; f.Nc = 2; f.Nf = a.Nf; f.H = a.H; f.W = a.W;
+    f.drop_invalid_rays = a.drop_invalid_rays;
+    f.image_coord = a.image_coord; f.inv_intrinsics = a.inv_intrinsics; f.parts = a.parts;
+    f.workspace = a.workspace;                    // no outputs: the set-up only writes records and the live list
+    if (int rc = launch_ray_setup(f, st)) return rc;
+    const int num_cus = device_cus();
+    if (num_cus <= 0) return host::fail((int)hipGetLastError(), "enarf_render_bwd: cannot query the device");
+    long long wgs = (long long)num_cus * kBwdWavesPerSimd;
+    const long long total = (long long)a.B * a.n;
+    if (wgs > total) wgs = total;
+    hipLaunchKernelGGL(render_bwd_kernel, dim3((unsigned)wgs), dim3(256), (size_t)bwd_lds_floats(a.P) * 4, st, a);
+    return host::check_launch("enarf_render_bwd");
+}
+
+extern "C" int enarf_triplane_unpack_add(const float *grad_feat_cl, float *grad_tri_nchw, int B, int channels_total,
+                                         int H, int W, enarf_stream_t stream) {
+    if (!grad_feat_cl || !grad_tri_nchw) return host::fail(ENARF_ERR_ARG, "enarf_triplane_unpack_add: null pointer");
+    if (B <= 0 || H <= 0 || W <= 0 || channels_total < 3 * ENARF_FEAT_DIM || H > 65535 || B * 3 > 65535)
+        return host::fail(ENARF_ERR_ARG, "enarf_triplane_unpack_add: bad sizes");
+    hipLaunchKernelGGL(unpack_add_kernel, dim3((W + 63) / 64, H, B * 3), dim3(256), 0, (hipStream_t)stream, grad_feat_cl,
+                       grad_tri_nchw, channels_total, H, W);
+    return host::check_launch("enarf_triplane_unpack_add");
+}
+
+extern "C" int enarf_prepare_bwd(const enarf_prepare_bwd_args *args, enarf_stream_t stream) {
+    if (!args) return host::fail(ENARF_ERR_ARG, "enarf_prepare_bwd: args is null");
+    const enarf_prepare_bwd_args &a = *args;
+    if (a.B <= 0 || a.B > 65535 || a.style_dim <= 0 || !a.z_rend || !a.d_z_rend)
+        return host::fail(ENARF_ERR_ARG, "enarf_prepare_bwd: bad sizes or null pointer");
+    for (int i = 0; i < 3; ++i)
+        if (!a.conv_weight[i] || !a.mod_weight[i] || !a.mod_bias[i] || !a.dW[i] || !a.d_conv_weight[i] || !a.d_mod_weight[i] ||
+            !a.d_mod_bias[i])
+            return host::fail(ENARF_ERR_ARG, "enarf_prepare_bwd: null pointer (layer %d)", i);
+    hipLaunchKernelGGL(prepare_bwd_kernel, dim3(3, a.B), dim3(256), 0, (hipStream_t)stream, a);
+    return host::check_launch("enarf_prepare_bwd");
+}

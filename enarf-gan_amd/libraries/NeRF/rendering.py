@@ -24,6 +24,47 @@ def _parts_from_part_poses(model, pose_to_camera: torch.Tensor, bone_length: tor
     return parts
 
 
+_MLP_LEAVES = ("conv.weight", "conv.modulation.weight", "conv.modulation.bias", "bias")
+
+
+class _RenderFunction(torch.autograd.Function):
+    """Differentiable wrapper of the fused march: forward = enarf_prepare (MLP pack) + enarf_triplane_pack +
+    enarf_render_fwd, backward = enarf_render_bwd + library GEMMs for dW' + enarf_prepare_bwd + un-pack.
+    Differentiable inputs: the tri-plane, z_rend and the 12 StyledMLP tensors (as in the reference, not the pose and
+    not the importance samples)."""
+
+    @staticmethod
+    def forward(ctx, k, tri, z_rend, *params):
+        mlp = {f"layers.{i}.{leaf}": params[4 * i + j] for i in range(3) for j, leaf in enumerate(_MLP_LEAVES)}
+        tri_c = tri.detach().contiguous()
+        feat_cl = ops.triplane_pack(tri_c)
+        pack = k["pack_fn"](z_rend.detach(), {n: t.detach() for n, t in mlp.items()})
+        out = ops.render_fwd(k["image_coord"], k["inv_intrinsics"], k["parts"], k["canonical_pose"], tri_c, feat_cl, pack,
+                             k["Nc"], k["Nf"], render_scale=k["render_scale"], bins=k["bins"], seed=k["seed"],
+                             mlp_mode=k["mlp_mode"], return_bins=True)
+        bins_used = out.taps["bins"]
+        ctx.k = k
+        ctx.save_for_backward(tri_c, feat_cl, pack, bins_used, z_rend.detach(), *[p.detach() for p in params])
+        ctx.mark_non_differentiable(out.fine_weights, out.fine_depth, bins_used)
+        return out.color, out.mask, out.disparity, out.fine_weights, out.fine_depth, bins_used
+
+    @staticmethod
+    def backward(ctx, g_color, g_mask, g_disp, _gfw, _gfd, _gb):
+        k = ctx.k
+        tri_c, feat_cl, pack, bins_used, z_rend = ctx.saved_tensors[:5]
+        params = ctx.saved_tensors[5:]
+        mlp = {f"layers.{i}.{leaf}": params[4 * i + j] for i in range(3) for j, leaf in enumerate(_MLP_LEAVES)}
+        grad_tri, dW, db = ops.render_bwd(k["image_coord"], k["inv_intrinsics"], k["parts"], k["canonical_pose"], tri_c,
+                                          feat_cl, pack, k["Nf"], bins_used, g_color, g_mask, g_disp,
+                                          render_scale=k["render_scale"])
+        pg, dz = ops.prepare_bwd(z_rend, mlp, dW)
+        grads = []
+        for i in range(3):
+            grads += [pg[f"layers.{i}.conv.weight"], pg[f"layers.{i}.conv.modulation.weight"],
+                      pg[f"layers.{i}.conv.modulation.bias"], db[i].reshape(params[4 * i + 3].shape)]
+        return (None, grad_tri, dz) + tuple(grads)
+
+
 def render(model, image_coord: torch.Tensor, pose_to_camera: torch.Tensor, inv_intrinsics: torch.Tensor,
            render_scale: float = 1, Nc: int = 64, Nf: int = 128, semantic_map: bool = False,
            return_intermediate: bool = False, camera_pose: Optional[torch.Tensor] = None,
@@ -40,23 +81,37 @@ def render(model, image_coord: torch.Tensor, pose_to_camera: torch.Tensor, inv_i
                                   "exposed by the fused kernel")
     if pose_to_camera.requires_grad:
         raise NotImplementedError("Currently pose should not be differentiable")   # rendering.py:216-217
-    if torch.is_grad_enabled() and any(p.requires_grad for p in model.parameters()):
-        raise NotImplementedError("backward of the fused renderer is not implemented yet (SURVEY.md §8f rank 1): "
-                                  "call under torch.no_grad()")
     assert pose_to_camera.shape[1] == model.num_bone
     if not hasattr(model, "buffers_tensors"):
         model.buffers_tensors = {}
-    tri, feat_cl = model._tri_plane_pair(model_input)
     if _parts is None:
         _parts = _parts_from_part_poses(model, pose_to_camera, model_input["bone_length"])
-    if _pack is None:
-        _pack = model._mlp_pack(model_input["z_rend"])
     if seed is None:
         seed = int(torch.randint(0, 2 ** 62, (1,)).item())
     cfg = model.config
+    mult_w = bool(cfg.multiply_density_with_triplane_wieght)
+    z_rend = model_input["z_rend"]
+    tri_graph = model._tri_plane_graph(model_input)        # tri-plane as the autograd graph sees it
+    params = model.mlp.as_dict()
+    needs_grad = torch.is_grad_enabled() and (tri_graph.requires_grad or z_rend.requires_grad or
+                                              any(p.requires_grad for p in params.values()))
+    if needs_grad:
+        if mult_w:
+            raise NotImplementedError("backward with multiply_density_with_triplane_wieght is not implemented")
+        k = dict(image_coord=image_coord.detach(), inv_intrinsics=inv_intrinsics.detach(), parts=_parts.detach(),
+                 canonical_pose=model.canonical_pose, Nc=Nc, Nf=Nf, render_scale=float(render_scale), bins=bins, seed=seed,
+                 mlp_mode=model.mlp_mode, pack_fn=model._mlp_pack_from)
+        flat = [params[f"layers.{i}.{leaf}"] for i in range(3) for leaf in _MLP_LEAVES]
+        color, mask, disparity, fw, fd, bins_used = _RenderFunction.apply(k, tri_graph, z_rend, *flat)
+        model.buffers_tensors.update(fine_weights=fw, fine_depth=fd, bins=bins_used, tri_plane_feature=tri_graph)
+        return color, mask, disparity
+    tri, feat_cl = model._tri_plane_pair(model_input)
+    if _pack is None:
+        _pack = model._mlp_pack(z_rend)
     out = ops.render_fwd(image_coord, inv_intrinsics, _parts, model.canonical_pose, tri, feat_cl, _pack, Nc, Nf,
                          render_scale=render_scale, bins=bins, seed=seed, mlp_mode=model.mlp_mode,
-                         multiply_density_with_weight=bool(cfg.multiply_density_with_triplane_wieght))
+                         multiply_density_with_weight=mult_w, return_bins=True)
+    model.buffers_tensors["bins"] = out.taps["bins"]
     model.buffers_tensors["fine_weights"] = out.fine_weights      # (B, 1, n, Nf-1); zeros for dropped rays
     model.buffers_tensors["fine_depth"] = out.fine_depth          # (B, 1, n, Nf)
     return out.color, out.mask, out.disparity

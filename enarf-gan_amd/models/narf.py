@@ -166,8 +166,22 @@ class TriPlaneNARF(nn.Module):
             self._cl_cache = (key, cl)
         return tri, cl
 
+    def _tri_plane_graph(self, model_input: Dict) -> torch.Tensor:
+        """The tri-plane tensor autograd should differentiate: the (1, ...) parameter itself for a constant tri-plane
+        (its expand() is undone so that the gradient is accumulated once, not per image), else the producer's output."""
+        tri = model_input.get("tri_plane_feature")
+        if tri is None:
+            if self.config.constant_triplane:
+                return self.tri_plane
+            tri = self.compute_tri_plane_feature(model_input.get("z"), model_input["bone_length"],
+                                                 model_input.get("truncation_psi", 1))
+        return tri
+
     def _mlp_pack(self, z_rend: torch.Tensor) -> torch.Tensor:
-        _, pack = ops_prepare_mlp_only(self, z_rend)
+        return self._mlp_pack_from(z_rend, self.mlp.as_dict())
+
+    def _mlp_pack_from(self, z_rend: torch.Tensor, mlp: Dict[str, torch.Tensor]) -> torch.Tensor:
+        _, pack = ops_prepare_mlp_only(self, z_rend, mlp)
         return pack
 
     # ---- the reference's entry points -------------------------------------------------------------------------------
@@ -218,12 +232,12 @@ class TriPlaneNARF(nn.Module):
         return den, col
 
 
-def ops_prepare_mlp_only(model: TriPlaneNARF, z_rend: torch.Tensor):
+def ops_prepare_mlp_only(model: TriPlaneNARF, z_rend: torch.Tensor, sd: Optional[Dict[str, torch.Tensor]] = None):
     """enarf_prepare with parts == NULL: only the per-image modulated MLP pack."""
     import ctypes as C
     from .. import _lib
     lib = _lib.load()
-    z = z_rend.float().contiguous()
+    z = z_rend.detach().float().contiguous()
     B = z.shape[0]
     a = _lib.PrepareArgs()
     a.B, a.num_joints, a.origin_location, a.style_dim = B, model.num_joints, _lib.ORIGIN[model.origin_location], z.shape[1]
@@ -232,7 +246,8 @@ def ops_prepare_mlp_only(model: TriPlaneNARF, z_rend: torch.Tensor):
         a.parents[j] = int(model.parent_id[j])
     a.z_rend = z.data_ptr()
     keep = []
-    sd = model.mlp.as_dict()
+    if sd is None:
+        sd = model.mlp.as_dict()
     for i in range(3):
         ts = [sd[f"layers.{i}.conv.weight"], sd[f"layers.{i}.conv.modulation.weight"],
               sd[f"layers.{i}.conv.modulation.bias"], sd[f"layers.{i}.bias"]]

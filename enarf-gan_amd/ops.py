@@ -233,7 +233,7 @@ def render_fwd(image_coord: torch.Tensor, inv_intrinsics: torch.Tensor, parts: t
                Nc: int, Nf: int, render_scale: float = 1.0, bins: Optional[torch.Tensor] = None, seed: int = 0,
                mlp_mode: str = "f32", multiply_density_with_weight: bool = False,
                drop_invalid_rays: Optional[bool] = None, want_fine: bool = True, debug: bool = False,
-               count: bool = False, early_stop_eps: float = 0.0) -> RenderOutputs:
+               count: bool = False, early_stop_eps: float = 0.0, return_bins: bool = False) -> RenderOutputs:
     """The fused ray march. image_coord (B,1,3,n) or (B,3,n); returns color (B,3,n), mask (B,n), disparity (B,n),
     fine_weights (B,1,n,Nf-1), fine_depth (B,1,n,Nf) and, with debug=True, the parity taps."""
     lib = _lib.load()
@@ -283,9 +283,109 @@ def render_fwd(image_coord: torch.Tensor, inv_intrinsics: torch.Tensor, parts: t
         a.dbg_coarse_density, a.dbg_fine_density = _p(t["coarse_density"]), _p(t["fine_density"])
         a.dbg_fine_color, a.dbg_fine_valid, a.dbg_bins = _p(t["fine_color"]), _p(t["fine_valid"]), _p(t["bins"])
         o.taps = t
+    if return_bins and not debug:      # the importance samples actually used (needed to replay / differentiate)
+        o.taps = {"bins": torch.empty(B, n, Nf, dtype=torch.float32, device=dev)}
+        a.dbg_bins = _p(o.taps["bins"])
     if count:
         o.counters = torch.zeros(4, dtype=torch.int64, device=dev)
         a.counters = _p(o.counters)
     a.workspace = _p(_render_workspace(dev, B, n))
     _lib.check(lib.enarf_render_fwd(C.byref(a), _stream(dev)), "enarf_render_fwd")
     return o
+
+
+# ---------------------------------------------------------------------------------------- backward
+def render_bwd(image_coord, inv_intrinsics, parts, canonical_pose, tri_nchw, feat_cl, mlp_pack, Nf, bins,
+               g_color, g_mask, g_disparity=None, render_scale: float = 1.0, drop_invalid_rays: Optional[bool] = None):
+    """Backward of render_fwd w.r.t. the tri-plane and the per-image demodulated MLP weights / biases.
+
+    Returns (grad_tri (same batch as tri_nchw: 1 for a shared tri-plane), dW [3 x (B,out,in)], db [3 x (out,)]).
+    The weight gradients are formed from the kernel's per-tile rows with a library GEMM (torch.matmul = rocBLAS)."""
+    lib = _lib.load()
+    coord = _dev_f32(image_coord, "image_coord")
+    B, n = coord.shape[0], coord.shape[-1]
+    coord = coord.reshape(B, 3, n)
+    Ki = _dev_f32(inv_intrinsics, "inv_intrinsics")
+    if Ki.dim() == 2:
+        Ki = Ki[None].expand(B, -1, -1).contiguous()
+    P = parts.shape[1]
+    tri = _dev_f32(tri_nchw, "tri_plane")
+    Ct, H, W = tri.shape[1:]
+    mstride, fstride = _plane_strides(tri, feat_cl, B)
+    dev = coord.device
+    rows = int(lib.enarf_render_bwd_rows_per_image(n, Nf))
+    bufs = {k: torch.empty(B, rows, w, dtype=torch.float32, device=dev)
+            for k, w in (("x", 32), ("h1", 64), ("h2", 64), ("dz1", 64), ("dz2", 64), ("dz3", 4))}
+    blocks = torch.zeros(B, dtype=torch.int32, device=dev)
+    grad_tri = torch.zeros_like(tri)
+    gfeat = torch.zeros_like(feat_cl)
+    a = _lib.RenderBwdArgs()
+    a.B, a.n, a.P, a.Nf, a.H, a.W = B, n, P, Nf, H, W
+    a.drop_invalid_rays = int(B == 1 if drop_invalid_rays is None else drop_invalid_rays)
+    a.render_scale = float(render_scale)
+    a.image_coord, a.inv_intrinsics, a.parts = _p(coord), _p(Ki), _p(parts)
+    a.canonical_pose = _p(_dev_f32(canonical_pose, "canonical_pose"))
+    a.feat_cl, a.feat_batch_stride = _p(feat_cl), fstride
+    a.mask_planes, a.mask_batch_stride = tri.data_ptr() + PLANE_CH * H * W * 4, mstride
+    a.mlp_pack = _p(mlp_pack)
+    bins = _dev_f32(bins, "bins").reshape(B, n, Nf)
+    a.bins = _p(bins)
+    gc = None if g_color is None else _dev_f32(g_color, "g_color").reshape(B, 3, n)
+    gm = None if g_mask is None else _dev_f32(g_mask, "g_mask").reshape(B, n)
+    gd = None if g_disparity is None else _dev_f32(g_disparity, "g_disparity").reshape(B, n)
+    a.g_color, a.g_mask, a.g_disparity = _p(gc), _p(gm), _p(gd)
+    a.grad_feat_cl, a.grad_feat_batch_stride = _p(gfeat), fstride
+    a.grad_mask_planes, a.grad_mask_batch_stride = grad_tri.data_ptr() + PLANE_CH * H * W * 4, mstride
+    a.rows_x, a.rows_h1, a.rows_h2 = _p(bufs["x"]), _p(bufs["h1"]), _p(bufs["h2"])
+    a.rows_dz1, a.rows_dz2, a.rows_dz3 = _p(bufs["dz1"]), _p(bufs["dz2"]), _p(bufs["dz3"])
+    a.rows_per_image, a.row_blocks = rows, _p(blocks)
+    a.workspace = _p(_render_workspace(dev, B, n))
+    _lib.check(lib.enarf_render_bwd(C.byref(a), _stream(dev)), "enarf_render_bwd")
+    _lib.check(lib.enarf_triplane_unpack_add(_p(gfeat), _p(grad_tri), grad_tri.shape[0], Ct, H, W, _stream(dev)),
+               "enarf_triplane_unpack_add")
+    # weight gradients per image: dW'_l = dZ_l^T H_{l-1}  (library GEMM over the rows the kernel wrote)
+    counts = (blocks.cpu().to(torch.int64) * 16).tolist()
+    dW = [torch.zeros(B, 64, 32, device=dev), torch.zeros(B, 64, 64, device=dev), torch.zeros(B, 4, 64, device=dev)]
+    db = [torch.zeros(64, device=dev), torch.zeros(64, device=dev), torch.zeros(4, device=dev)]
+    for b in range(B):
+        r = counts[b]
+        if r == 0:
+            continue
+        ins = (bufs["x"][b, :r], bufs["h1"][b, :r], bufs["h2"][b, :r])
+        dzs = (bufs["dz1"][b, :r], bufs["dz2"][b, :r], bufs["dz3"][b, :r])
+        for l in range(3):
+            dW[l][b] = dzs[l].t() @ ins[l]
+            db[l] += dzs[l].sum(dim=0)
+    return grad_tri, dW, db
+
+
+def prepare_bwd(z_rend: torch.Tensor, mlp: Dict[str, torch.Tensor], dW):
+    """dW' (3 x (B,out,in)) -> gradients of conv.weight, modulation.weight, modulation.bias (summed over the batch,
+    in the parameters' own shapes) and of z_rend (B, style_dim)."""
+    lib = _lib.load()
+    z = _dev_f32(z_rend, "z_rend")
+    B, D = z.shape
+    dev = z.device
+    a = _lib.PrepareBwdArgs()
+    a.B, a.style_dim, a.z_rend = B, D, _p(z)
+    keep, outs = [], []
+    dims = [(FEAT_DIM, 64), (64, 64), (64, 4)]
+    for i, (cin, cout) in enumerate(dims):
+        cw = _dev_f32(mlp[f"layers.{i}.conv.weight"].detach(), "conv.weight")
+        mw = _dev_f32(mlp[f"layers.{i}.conv.modulation.weight"].detach(), "modulation.weight")
+        mb = _dev_f32(mlp[f"layers.{i}.conv.modulation.bias"].detach(), "modulation.bias")
+        d = _dev_f32(dW[i], "dW")
+        o = (torch.empty(B, cout, cin, device=dev), torch.empty(B, cin, D, device=dev), torch.empty(B, cin, device=dev))
+        keep += [cw, mw, mb, d]
+        outs.append(o)
+        a.conv_weight[i], a.mod_weight[i], a.mod_bias[i], a.dW[i] = _p(cw), _p(mw), _p(mb), _p(d)
+        a.d_conv_weight[i], a.d_mod_weight[i], a.d_mod_bias[i] = _p(o[0]), _p(o[1]), _p(o[2])
+    dz = torch.empty(B, 3, D, device=dev)
+    a.d_z_rend = _p(dz)
+    _lib.check(lib.enarf_prepare_bwd(C.byref(a), _stream(dev)), "enarf_prepare_bwd")
+    grads = {}
+    for i, (cin, cout) in enumerate(dims):
+        grads[f"layers.{i}.conv.weight"] = outs[i][0].sum(0).reshape(1, cout, cin, 1)
+        grads[f"layers.{i}.conv.modulation.weight"] = outs[i][1].sum(0)
+        grads[f"layers.{i}.conv.modulation.bias"] = outs[i][2].sum(0)
+    return grads, dz.sum(1)

@@ -203,6 +203,54 @@ typedef struct {
 size_t enarf_render_workspace_bytes(int B, int n);
 int enarf_render_fwd(const enarf_render_args *args, enarf_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Backward of the fused renderer: what `loss_gen.backward()` computes through render
+ * (libraries/NeRF/rendering.py:283-335), the fine-pass query (models/narf.py:176-275), the StyledMLP and MyReLU's
+ * custom backward (libraries/NeRF/activation.py:12-16). As in the reference, gradients flow through the FINE pass
+ * only (the importance samples are not differentiable) and not into poses.
+ *   enarf_render_bwd   d loss / d tri-plane (atomically accumulated into caller-zeroed buffers) and, per valid
+ *                      16-sample tile, the rows (x, h1, h2, dz1, dz2, dz3) from which the caller forms the weight
+ *                      gradients dW'_l = dZ_l^T H_{l-1} with a library GEMM, per image.
+ *   enarf_prepare_bwd  d loss / d (conv.weight, modulation.weight, modulation.bias, z_rend) from dW' (the backward of
+ *                      ModulatedConv1d's modulate + F.normalize), per image; the caller sums the shared parameters.
+ *   enarf_triplane_unpack_add   grad_tri[:, :96] += channel-last gradient (inverse of enarf_triplane_pack).
+ * --------------------------------------------------------------------------------------------- */
+typedef struct {
+    int B, n, P, Nf, H, W;
+    int drop_invalid_rays;
+    float render_scale;
+    const float *image_coord, *inv_intrinsics, *parts, *canonical_pose;
+    const float *feat_cl; long long feat_batch_stride;
+    const float *mask_planes; long long mask_batch_stride;
+    const void *mlp_pack;
+    const float *bins;                    /* device (B, n, Nf): the bins the forward used (its dbg_bins output) */
+    const float *g_color, *g_mask, *g_disparity;   /* upstream gradients (B,3,n), (B,n), (B,n); NULL = zero */
+    float *grad_feat_cl; long long grad_feat_batch_stride;      /* (B|1, 3, H, W, 32), zero-filled by the caller */
+    float *grad_mask_planes; long long grad_mask_batch_stride;  /* &grad_tri[0][96][0][0], zero-filled by the caller */
+    float *rows_x, *rows_h1, *rows_h2, *rows_dz1, *rows_dz2, *rows_dz3;   /* (B, rows_per_image, 32|64|64|64|64|4) */
+    long long rows_per_image;             /* >= enarf_render_bwd_rows_per_image(n, Nf) */
+    unsigned int *row_blocks;             /* device (B,): 16-row blocks written per image (zeroed by the call) */
+    void *workspace;                      /* as enarf_render_fwd */
+} enarf_render_bwd_args;
+
+long long enarf_render_bwd_rows_per_image(int n, int Nf);
+int enarf_render_bwd(const enarf_render_bwd_args *args, enarf_stream_t stream);
+
+typedef struct {
+    int B, style_dim;
+    const float *z_rend;                  /* (B, style_dim) */
+    const float *conv_weight[3], *mod_weight[3], *mod_bias[3];   /* as enarf_prepare_args */
+    const float *dW[3];                   /* (B, out, in) dense row-major gradients of the demodulated weights */
+    float *d_conv_weight[3];              /* (B, out, in)       per image */
+    float *d_mod_weight[3];               /* (B, in, style_dim) per image */
+    float *d_mod_bias[3];                 /* (B, in)            per image */
+    float *d_z_rend;                      /* (B, 3, style_dim)  per image and layer */
+} enarf_prepare_bwd_args;
+int enarf_prepare_bwd(const enarf_prepare_bwd_args *args, enarf_stream_t stream);
+
+int enarf_triplane_unpack_add(const float *grad_feat_cl, float *grad_tri_nchw, int B, int channels_total, int H, int W,
+                              enarf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -275,6 +275,21 @@ def styled_mlp(feature: torch.Tensor, weights: List[Tuple[torch.Tensor, torch.Te
     return h
 
 
+class MyReLU(torch.autograd.Function):
+    """libraries/NeRF/activation.py:5-16: ReLU whose backward lets negative gradients through the negative region
+    with slope 0.1 ("avoid zero gradient in the negative region")."""
+
+    @staticmethod
+    def forward(ctx, inp):
+        ctx.save_for_backward(inp)
+        return F.relu(inp)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        inp, = ctx.saved_tensors
+        return grad_output * (inp >= 0) + grad_output * (inp < 0) * (grad_output < 0) * 0.1
+
+
 # ----------------------------------------------------------------------------- the query (a9)
 def query(points: torch.Tensor, pose_scaled: torch.Tensor, scale: torch.Tensor,
           canonical_pose: torch.Tensor, tri_plane: torch.Tensor,
@@ -291,7 +306,7 @@ def query(points: torch.Tensor, pose_scaled: torch.Tensor, scale: torch.Tensor,
     feat = weighted_feature(tri_plane[:, :3 * FEAT_DIM], canonical, w, valid, use_grid_sample)
     h = styled_mlp(feat, weights)
     color = torch.tanh(h[:, :3])
-    density = F.relu(h[:, 3:])
+    density = MyReLU.apply(h[:, 3:])
     if multiply_density_with_weight:
         density = density * (10 * w.max(dim=1, keepdim=True)[0])
     else:

@@ -1,0 +1,82 @@
+"""Backward of the fused renderer against autograd through the oracle.
+
+The oracle is plain torch, so `torch.autograd` through it IS the reference's gradient (same ops, incl. MyReLU's
+custom backward, libraries/NeRF/activation.py:12-16). Tolerance: 1e-3 of each gradient tensor's max magnitude
+(float atomics and a different summation order; the forward bound of 1e-4 applies to values, not to gradients)."""
+import numpy as np
+import pytest
+import torch
+
+from _helpers import DeviceScene, Scene, assert_close
+from oracle import enarf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_grads(sc, coord, Nc, Nf, bins, gc, gm, gd):
+    s = sc.raw
+    tri = s["tri_plane"].clone().requires_grad_(True)
+    mlp = {k: v.clone().requires_grad_(True) for k, v in s["mlp"].items() if "noise" not in k}
+    z = s["z_rend"].clone().requires_grad_(True)
+    rc, rm, rd = O.render(coord, sc.pose_parts, sc.bl_parts, s["inv_intrinsics"], sc.cpose, sc.cbl, tri, mlp, z,
+                          sc.cs, Nc, Nf, bins=bins)
+    loss = (rc * gc).sum() + (rm * gm).sum() + (rd * gd).sum()
+    keys = sorted(mlp)
+    grads = torch.autograd.grad(loss, [tri, z] + [mlp[k] for k in keys])
+    return grads[0], grads[1], dict(zip(keys, grads[2:]))
+
+
+@pytest.mark.parametrize("B,size,style_dim,n_rays", [(1, 32, 20, 72), (2, 32, 256, 48)])
+def test_render_backward_matches_oracle_autograd(B, size, style_dim, n_rays):
+    from enarf_gan_amd import ops
+    sc = Scene(size, B, "center_fixed", style_dim)
+    ds = DeviceScene(sc)
+    Nc, Nf = 48, 32
+    n = size * size
+    start = n // 2 - n_rays // 2                      # a band through the body
+    coord = sc.raw["image_coord"][..., start:start + n_rays].contiguous()
+    fwd = ds.render(coord, Nc, Nf, None, seed=7, debug=True, mlp_mode="f32")
+    bins = fwd.taps["bins"].cpu()
+    g = torch.Generator().manual_seed(5)
+    gc, gm, gd = torch.randn(B, 3, n_rays, generator=g), torch.randn(B, n_rays, generator=g), torch.randn(B, n_rays, generator=g)
+    o_tri, o_z, o_mlp = _oracle_grads(sc, coord, Nc, Nf, bins, gc, gm, gd)
+
+    grad_tri, dW, db = ops.render_bwd(coord.cuda(), ds.inv_K, ds.parts, ds.cpose, ds.tri, ds.feat_cl, ds.pack, Nf,
+                                      bins.cuda(), gc.cuda(), gm.cuda(), gd.cuda())
+    pg, dz = ops.prepare_bwd(sc.raw["z_rend"].cuda(), ds.mlp, dW)
+    # tri-plane: feature planes and part-probability planes separately (different magnitudes)
+    assert float(o_tri[:, :96].abs().max()) > 0 and float(o_tri[:, 96:].abs().max()) > 0
+    assert_close(grad_tri[:, :96].cpu(), o_tri[:, :96], "d loss / d feature planes", 1e-3)
+    assert_close(grad_tri[:, 96:].cpu(), o_tri[:, 96:], "d loss / d part-probability planes", 1e-3)
+    for l in range(3):
+        assert_close(db[l].cpu(), o_mlp[f"layers.{l}.bias"].reshape(-1), f"d bias {l}", 1e-3)
+        for leaf in ("conv.weight", "conv.modulation.weight", "conv.modulation.bias"):
+            assert_close(pg[f"layers.{l}.{leaf}"].cpu(), o_mlp[f"layers.{l}.{leaf}"], f"d layers.{l}.{leaf}", 1e-3)
+    assert_close(dz.cpu(), o_z, "d z_rend", 1e-3)
+
+
+def test_model_forward_is_differentiable():
+    """The mirror model under autograd: tri_plane (parameter), MLP parameters and z_rend receive the oracle's gradients."""
+    from test_gpu_api import _model
+    sc = Scene(32, 1, "center_fixed", 20)
+    m = _model(sc, Nc=48, Nf=32, style_dim=20, mlp_mode="f32").train()
+    n_rays = 64
+    start = 32 * 14
+    coord = sc.raw["image_coord"][..., start:start + n_rays].contiguous()
+    s = sc.raw
+    z = s["z_rend"].cuda().requires_grad_(True)
+    with torch.no_grad():
+        probe = m(1, coord.cuda(), s["pose_to_camera"].cuda(), s["inv_intrinsics"].cuda(), None, z.detach(),
+                  s["bone_length"].cuda(), Nc=48, Nf=32, seed=3)
+    bins = m.buffers_tensors["bins"].clone()
+    color, mask = m(1, coord.cuda(), s["pose_to_camera"].cuda(), s["inv_intrinsics"].cuda(), None, z, s["bone_length"].cuda(),
+                    Nc=48, Nf=32, bins=bins)
+    assert torch.equal(color.detach(), probe[0])
+    g = torch.Generator().manual_seed(1)
+    gc, gm = torch.randn(1, 3, n_rays, generator=g), torch.randn(1, n_rays, generator=g)
+    ((color * gc.cuda()).sum() + (mask * gm.cuda()).sum()).backward()
+    o_tri, o_z, o_mlp = _oracle_grads(sc, coord, 48, 32, bins.cpu(), gc, gm, torch.zeros(1, n_rays))
+    assert_close(m.tri_plane.grad.cpu(), o_tri, "tri_plane.grad", 1e-3)
+    assert_close(z.grad.cpu(), o_z, "z_rend.grad", 1e-3)
+    assert_close(m.mlp.layers[1].conv.weight.grad.cpu(), o_mlp["layers.1.conv.weight"], "layers.1.conv.weight.grad", 1e-3)
+    assert_close(m.mlp.layers[2].bias.grad.cpu(), o_mlp["layers.2.bias"], "layers.2.bias.grad", 1e-3)
