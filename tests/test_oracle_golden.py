@@ -130,3 +130,31 @@ def test_linspace_formula_is_torch_linspace():
         ours = O.linspace_sym(a, b, n)
         ref = torch.linspace(a, b, n)
         assert torch.allclose(ours, ref, rtol=0, atol=2e-7 * max(abs(a), abs(b), 1.0))
+
+
+@pytest.mark.parametrize("name", ["grad_32_b1", "grad_32_b2"])
+def test_oracle_autograd_matches_reference_gradients(golden_dir, name):
+    """Autograd through the oracle (incl. its MyReLU restatement) against the reference's own autograd."""
+    import torch.nn.functional as F
+    g = _load(golden_dir, name)
+    B, ol, sd = int(g["batch"]), str(g["origin_location"]), int(g["style_dim"])
+    scene = synth.make_scene(int(g["size"]), B, ol, sd)
+    pose_p, bl_p = O.transform_pose(scene["pose_to_camera"], scene["bone_length"], ol, scene["parents"])
+    cpose, cbl = O.register_canonical_pose(scene["canonical_pose"], scene["parents"], ol)
+    s0, nr = int(g["start"]), int(g["n_rays"])
+    coord = scene["image_coord"][..., s0:s0 + nr].contiguous()
+    tri = scene["tri_plane"].clone().requires_grad_(True)
+    mlp = {k: v.clone().requires_grad_(True) for k, v in scene["mlp"].items() if "noise" not in k}
+    z = scene["z_rend"].clone().requires_grad_(True)
+    rc, rm, rd = O.render(coord, pose_p, bl_p, scene["inv_intrinsics"], cpose, cbl, tri, mlp, z, 3.0, int(g["Nc"]),
+                          int(g["Nf"]), bins=torch.from_numpy(g["bins"]))
+    _assert_close(rc.detach(), g["color"], "colour")
+    loss = (rc * torch.from_numpy(g["g_color"])).sum() + (rm * torch.from_numpy(g["g_mask"])).sum() + \
+        (rd * torch.from_numpy(g["g_disp"])).sum()
+    keys = sorted(mlp)
+    grads = torch.autograd.grad(loss, [tri, z] + [mlp[k] for k in keys])
+    _assert_close(F.avg_pool2d(grads[0], 16) * 256, g["grad_tri_pool16"], "d tri-plane (16x16 sum-pooled)", 1e-3)
+    assert abs(float(grads[0].abs().sum()) - float(g["grad_tri_abs_sum"])) < 1e-3 * float(g["grad_tri_abs_sum"])
+    _assert_close(grads[1], g["grad_z"], "d z_rend", 1e-3)
+    for k, gk in zip(keys, grads[2:]):
+        _assert_close(gk, g["grad_" + k], "d " + k, 1e-3)
