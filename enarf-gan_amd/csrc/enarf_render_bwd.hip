@@ -27,22 +27,48 @@ constexpr int SB_DZ3 = 448;       // dL/dz3 [4][64]
 constexpr int SB_QUEUE = 704;     // 2 ray ids
 static_assert(SB_QUEUE + 2 <= kScratchFloats, "scratch overflow");
 
+constexpr int kTRow = 33;                       // floats per texel row of the transpose tile (32 + 1 pad)
+constexpr int kTTile = 16 * kTRow + 16;          // 16 texel rows + 16 texel offsets (ints)
 __host__ __device__ inline int bwd_lds_floats(int P) {
-    return PK_B1 + 144 + PKT_FLOATS + P * kLdsPartStride + P * kLdsCanonStride + kScratchFloats;
+    return PK_B1 + 144 + PKT_FLOATS + P * kLdsPartStride + P * kLdsCanonStride + kScratchFloats + 4 * kTTile;
 }
 
-// d loss / d the 4 texels of one plane, this lane's 8 channels: grad[texel][c] += bilinear weight * w_k * dx[c]
-__device__ __forceinline__ void scatter_tap(float *__restrict__ dst, float cf, const float dxg[8]) {
-    if (cf != 0.0f) {
+// d loss / d one tap (texel) of every quad of the wave: grad[texel][c] += bilinear weight * w_k * dx[c].
+// A quad holds the 32 channel values of its texel as 4 lanes x 8; float atomics only run at full rate when one
+// wave-instruction covers whole 128-B lines (MI355X_MICROARCH.md, Global float atomics: 64 scattered dwords are
+// ~17x slower), so the 16 x 32 values go through a per-wave LDS tile and come back as lane = (texel pair, channel):
+// 8 atomic instructions, each adding into two contiguous 128-B texel lines.
+__device__ __forceinline__ void scatter_tap(float *__restrict__ gpl, float *tile, int off, float cf, bool on,
+                                            const float dxg[8], int lane) {
+    const int q = lane >> 2, g = lane & 3;
+    int *toff = reinterpret_cast<int *>(tile + 16 * kTRow);
+    const bool live = on && cf != 0.0f;
+    f32x4 *row = reinterpret_cast<f32x4 *>(tile + q * kTRow + 8 * g);      // 33-float rows: not 16-B aligned -> b32 stores
+    float *rowf = tile + q * kTRow + 8 * g;
+    (void)row;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) atomicAdd(dst + c, cf * dxg[c]);
+    for (int c = 0; c < 8; ++c) rowf[c] = live ? cf * dxg[c] : 0.0f;
+    if (g == 0) toff[q] = live ? off : -1;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int tq = 2 * i + (lane >> 5), ch = lane & 31;
+        const int o = toff[tq];
+        const float v = tile[tq * kTRow + ch];
+        if (o >= 0) atomicAdd(gpl + (size_t)o * kFeat + ch, v);
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-__device__ __forceinline__ void scatter_plane(float *__restrict__ gpl, const Taps &t, float wk, const float dxg[8]) {
-    scatter_tap(gpl + (size_t)t.o00 * kFeat, t.w00 * wk, dxg);
-    scatter_tap(gpl + (size_t)t.o01 * kFeat, t.w01 * wk, dxg);
-    scatter_tap(gpl + (size_t)t.o10 * kFeat, t.w10 * wk, dxg);
-    scatter_tap(gpl + (size_t)t.o11 * kFeat, t.w11 * wk, dxg);
+__device__ __forceinline__ void scatter_plane(float *__restrict__ gpl, float *tile, const Taps &t, float wk, bool on,
+                                              const float dxg[8], int lane) {
+    scatter_tap(gpl, tile, t.o00, t.w00 * wk, on, dxg, lane);
+    scatter_tap(gpl, tile, t.o01, t.w01 * wk, on, dxg, lane);
+    scatter_tap(gpl, tile, t.o10, t.w10 * wk, on, dxg, lane);
+    scatter_tap(gpl, tile, t.o11, t.w11 * wk, on, dxg, lane);
 }
 
 __global__ __launch_bounds__(256, kBwdWavesPerSimd) void render_bwd_kernel(const enarf_render_bwd_args a) {
@@ -70,6 +96,7 @@ __global__ __launch_bounds__(256, kBwdWavesPerSimd) void render_bwd_kernel(const
     S.H = a.H; S.W = a.W; S.P = P; S.mult_w = 0; S.ablate = 0;
     int *l_cand = reinterpret_cast<int *>(scratch + SB_CAND) + wave * 32;
     float *l_fh = scratch + SB_FH, *l_dz3 = scratch + SB_DZ3;
+    float *ttile = scratch + kScratchFloats + wave * kTTile;     // this wave's atomic-transpose tile
     uint32_t *l_fbits = reinterpret_cast<uint32_t *>(scratch + SB_FBITS);
     const int Tf = (Nf + 3) >> 2;
     const int j4 = lane >> 2, g4 = lane & 3;
@@ -300,20 +327,18 @@ __global__ __launch_bounds__(256, kBwdWavesPerSimd) void render_bwd_kernel(const
                 }
                 dot += quad_perm_f<0xB1>(dot);
                 dot += quad_perm_f<0x4E>(dot);                                  // d loss / d w_k, quad-uniform
-                if (act) {
-                    if (g4 < 3) {   // w = s0 s1 s2, s = sigmoid(m): dw/dm_g = w (1 - s_g)
-                        const float gm = dot * wk * (1.0f - sg);
-                        float *gp = gmask + (size_t)(3 * k + g4) * mplane;
-                        if (t.w00 != 0.0f) atomicAdd(gp + t.o00, t.w00 * gm);
-                        if (t.w01 != 0.0f) atomicAdd(gp + t.o01, t.w01 * gm);
-                        if (t.w10 != 0.0f) atomicAdd(gp + t.o10, t.w10 * gm);
-                        if (t.w11 != 0.0f) atomicAdd(gp + t.o11, t.w11 * gm);
-                    }
-                    float *gf = gfeat + 8 * g4;
-                    scatter_plane(gf, t0, wk, dxg);
-                    scatter_plane(gf + fplane, t1, wk, dxg);
-                    scatter_plane(gf + 2 * fplane, t2, wk, dxg);
+                if (act && g4 < 3) {   // w = s0 s1 s2, s = sigmoid(m): dw/dm_g = w (1 - s_g)
+                    const float gm = dot * wk * (1.0f - sg);
+                    float *gp = gmask + (size_t)(3 * k + g4) * mplane;
+                    if (t.w00 != 0.0f) atomicAdd(gp + t.o00, t.w00 * gm);
+                    if (t.w01 != 0.0f) atomicAdd(gp + t.o01, t.w01 * gm);
+                    if (t.w10 != 0.0f) atomicAdd(gp + t.o10, t.w10 * gm);
+                    if (t.w11 != 0.0f) atomicAdd(gp + t.o11, t.w11 * gm);
                 }
+                // every lane takes part (wave-uniform): inactive quads contribute empty rows
+                scatter_plane(gfeat, ttile, t0, wk, act, dxg, lane);
+                scatter_plane(gfeat + fplane, ttile, t1, wk, act, dxg, lane);
+                scatter_plane(gfeat + 2 * fplane, ttile, t2, wk, act, dxg, lane);
             }
         }
         // the next ray's first barrier orders this ray's LDS reads (l_dz3, l_fh) before their next writes
