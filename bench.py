@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--origin", default="center_fixed", choices=["center", "center_fixed", "center+head"])
     ap.add_argument("--mlp-mode", default="f16x3", choices=["f32", "f16x3", "bf16x3", "bf16"])
     ap.add_argument("--style-dim", type=int, default=20)
+    ap.add_argument("--early-stop-eps", type=float, default=0.0, help="opt-in early ray termination (0 = exact)")
     ap.add_argument("--cache-triplane", action="store_true",
                     help="re-lay the (constant) tri-plane once instead of every step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -111,12 +112,13 @@ def main():
         if not args.cache_triplane:
             ops.triplane_pack(tri, feat_cl)
         return ops.render_fwd(coord, d["inv_intrinsics"], parts, cpose_d, tri, feat_cl, pack, Nc, Nf,
-                              seed=99 + i, mlp_mode=args.mlp_mode, want_fine=True, count=count)
+                              seed=99 + i, mlp_mode=args.mlp_mode, want_fine=True, count=count,
+                              early_stop_eps=args.early_stop_eps)
 
     # algorithmic work of one step, counted by the kernel itself in an untimed pass (same inputs, same seed)
     cnt = step(0, count=True).counters
     torch.cuda.synchronize()
-    V, tiles, rays_marched = [int(x) for x in cnt[:3].tolist()]
+    V, tiles, rays_marched, rounds = [int(x) for x in cnt[:4].tolist()]
 
     for i in range(args.warmup):
         step(i)
@@ -133,7 +135,7 @@ def main():
             ops.triplane_pack(tri, feat_cl)
         ev0[i].record()
         ops.render_fwd(coord, d["inv_intrinsics"], parts, cpose_d, tri, feat_cl, pack, Nc, Nf, seed=99,
-                       mlp_mode=args.mlp_mode, want_fine=True)
+                       mlp_mode=args.mlp_mode, want_fine=True, early_stop_eps=args.early_stop_eps)
         ev1[i].record()
     torch.cuda.synchronize()
     if dist is not None:
@@ -166,12 +168,13 @@ def main():
             "config": {"workload": f"C1: DSO-style {S}x{S} frame, Nc {Nc} + Nf {Nf} samples/ray, 24 joints -> P={P} parts "
                                    f"({args.origin}), {B} frame/GPU/step, constant fp32 tri-plane 256^2x(96+{3 * P}), "
                                    f"in-kernel Philox importance sampling",
-                       "mlp_arith": args.mlp_mode, "triplane_relayout_in_step": not args.cache_triplane,
+                       "mlp_arith": args.mlp_mode, "early_stop_eps": args.early_stop_eps, "triplane_relayout_in_step": not args.cache_triplane,
                        "step": "enarf_prepare + enarf_triplane_pack + enarf_render_fwd"},
             "roofline": {"bound": "hbm", "kernel": "enarf::render_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes,
                          "valid_part_point_pairs": V, "rays_marched": rays_marched, "mlp_tiles_of_16": tiles,
+                         "gather_rounds": rounds, "gather_lane_utilisation": V / max(16 * rounds, 1),
                          "mfma_eligible_tflops": q * 12800 / (kern_ms * 1e-3) / 1e12,
                          "mfma_frac_of_bf16_dense_peak": q * 12800 / (kern_ms * 1e-3) / 1e12 / BF16_DENSE_TFLOPS},
         }

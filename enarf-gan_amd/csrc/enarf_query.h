@@ -365,7 +365,8 @@ __device__ __forceinline__ void load_frames(const QueryCtx &S, int k, float F[13
 template <int MODE, bool DBG>
 __device__ __forceinline__ void query_tile(const QueryCtx &S, const int *cand_list, int ncand, float px, float py,
                                            float pz, bool active, int lane, f32x4 &o, bool &ran, uint32_t &bits,
-                                           float &wmax, const QueryDbg &dbg, unsigned &n_pairs, unsigned &n_tiles) {
+                                           float &wmax, const QueryDbg &dbg, unsigned &n_pairs, unsigned &n_tiles,
+                                           unsigned *n_rounds = nullptr) {
     const int g = lane & 3;
     uint32_t mine = 0;
     for (int i0 = 0; i0 < ncand; i0 += 4) {
@@ -479,6 +480,7 @@ __device__ __forceinline__ void query_tile(const QueryCtx &S, const int *cand_li
         }
 #endif
         n_pairs += (unsigned)(__popcll(bal) >> 2);
+        if (n_rounds) *n_rounds += 1;
     }
 
     ran = (__ballot(b != 0) != 0) && !(S.ablate & 4);

@@ -437,7 +437,7 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
     if (tid <= Nc) l_btab[tid] = linspace_sym(0.0f, 1.0f, Nc + 1, tid);
     __syncthreads();
 
-    unsigned n_pairs = 0, n_tiles = 0, n_rays = 0;
+    unsigned n_pairs = 0, n_tiles = 0, n_rays = 0, n_rounds = 0, n_skipped = 0;
     int qslot = 0;
     const QueryDbg nodbg{nullptr, nullptr, 0, 0};
     const int Tc = (Nc + 3) >> 2, Tf = (Nf + 3) >> 2;     // samples per wave (<= 16)
@@ -485,7 +485,7 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
             bool ran;
             uint32_t bits;
             float wmax;
-            query_tile<MODE, false>(S, l_cand, ncand, px, py, pz, active, lane, o, ran, bits, wmax, nodbg, n_pairs, n_tiles);
+            query_tile<MODE, false>(S, l_cand, ncand, px, py, pz, active, lane, o, ran, bits, wmax, nodbg, n_pairs, n_tiles, &n_rounds);
             if (lane < Tc && wave * Tc + lane < Nc) l_ch[wave * Tc + lane] = o[3];
             if (active && (lane & 3) == 0) { l_cbits[i] = bits; l_cwmax[i] = wmax; }
         }
@@ -495,6 +495,7 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
 
         // ---- S2 (every wave, lane = sample): weights (rendering.py:180-184), smoothing (:187-190), bins (:192-197)
         float bin;
+        bool skip_tile;
         {
             const bool active = lane < Nc;
             const int ci = min(lane, Nc - 1);
@@ -538,24 +539,35 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
                 bin = (lane < Nf) ? ((float)lo + frac) / (float)Nc : 3.0e38f;
             }
             if (a.dbg_bins && lane < Nf && wave == 0) a.dbg_bins[((size_t)b * n + ray) * Nf + lane] = bin;
+            // early ray termination (opt-in, early_stop_eps > 0): transmittance in front of this wave's first fine
+            // sample, read off the coarse pass (T before coarse bin j = exp(-(cs_j - dd_j))). Once it is below eps every
+            // sample of the tile weighs < eps: the tile's gathers and MLP are skipped (its densities count as 0).
+            skip_tile = false;
+            if (a.early_stop_eps > 0.0f) {
+                const float b_first = __shfl(bin, min(wave * Tf, Nf - 1));
+                const int jbin = min(max((int)(b_first * (float)Nc), 0), Nc - 1);
+                const float T_first = __shfl(T, jbin);
+                skip_tile = T_first < a.early_stop_eps;
+            }
         }
 
         // ---- S3: fine pass, wave w owns samples [w Tf, (w+1) Tf); the last sample only closes the last interval
         {
             const int i = wave * Tf + j4;
-            const bool active = (j4 < Tf) && (i < (dbgq ? Nf : Nf - 1));
+            const bool active = (j4 < Tf) && (i < (dbgq ? Nf : Nf - 1)) && !skip_tile;
             const float bi = __shfl(bin, min(i, Nf - 1));
             const float px = exact_lerp(sx, ex, bi), py = exact_lerp(sy, ey, bi), pz = exact_lerp(sz, ez, bi);
             f32x4 o;
             bool ran;
             uint32_t bits;
             float wmax;
-            query_tile<MODE, false>(S, l_cand, ncand, px, py, pz, active, lane, o, ran, bits, wmax, nodbg, n_pairs, n_tiles);
+            query_tile<MODE, false>(S, l_cand, ncand, px, py, pz, active, lane, o, ran, bits, wmax, nodbg, n_pairs, n_tiles, &n_rounds);
             if (lane < Tf && wave * Tf + lane < Nf) {
                 const int io = wave * Tf + lane;
                 l_fh[io] = o[0]; l_fh[64 + io] = o[1]; l_fh[128 + io] = o[2]; l_fh[192 + io] = o[3];
             }
             if ((j4 < Tf) && (i < Nf) && (lane & 3) == 0) { l_fbits[i] = active ? bits : 0u; l_fwmax[i] = wmax; }
+            if (skip_tile && lane == 0) n_skipped += 1;
         }
         __syncthreads();
 
@@ -604,6 +616,8 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
         atomicAdd(&a.counters[0], (unsigned long long)n_pairs);
         atomicAdd(&a.counters[1], (unsigned long long)n_tiles);
         atomicAdd(&a.counters[2], (unsigned long long)n_rays);
+        atomicAdd(&a.counters[3], (unsigned long long)n_rounds);
+        atomicAdd(&a.counters[4], (unsigned long long)n_skipped);
     }
 }
 

@@ -287,7 +287,7 @@ def render_fwd(image_coord: torch.Tensor, inv_intrinsics: torch.Tensor, parts: t
         o.taps = {"bins": torch.empty(B, n, Nf, dtype=torch.float32, device=dev)}
         a.dbg_bins = _p(o.taps["bins"])
     if count:
-        o.counters = torch.zeros(4, dtype=torch.int64, device=dev)
+        o.counters = torch.zeros(8, dtype=torch.int64, device=dev)
         a.counters = _p(o.counters)
     a.workspace = _p(_render_workspace(dev, B, n))
     _lib.check(lib.enarf_render_fwd(C.byref(a), _stream(dev)), "enarf_render_fwd")

@@ -167,7 +167,8 @@ typedef struct {
     int multiply_density_with_weight;
     int drop_invalid_rays;                /* the reference does this iff batchsize == 1 */
     float render_scale;
-    float early_stop_eps;                 /* 0 = exact; > 0 skips MLP work once transmittance < eps */
+    float early_stop_eps;                 /* 0 = exact (default). > 0: a quarter of the fine samples is skipped when the
+                                             coarse pass puts the transmittance in front of it below eps */
     const float *image_coord;             /* device (B, 3, n) homogeneous pixel coords */
     const float *inv_intrinsics;          /* device (B, 3, 3) */
     const float *parts;                   /* device (B, P, 16) */
@@ -193,7 +194,8 @@ typedef struct {
     uint32_t *dbg_fine_valid;             /* (B, n, Nf) bit masks */
     float *dbg_bins;                      /* (B, n, Nf) the bins actually used */
     unsigned long long *counters;         /* [0] valid (part,point) pairs sampled, [1] MLP tiles of 16 points run,
-                                             [2] rays marched; atomically accumulated; NULL = not counted */
+                                             [2] rays marched, [3] gather rounds (wave-level), [4] fine tiles skipped by early_stop_eps; (5 x u64) atomically
+                                             accumulated; NULL = not counted */
     void *workspace;                      /* device, >= enarf_render_workspace_bytes(B, n): queue head, per-ray records
                                              (depth range, candidate parts) and the live-ray list. The call zeroes
                                              the header on `stream` (hipMemsetAsync); one workspace must not be

@@ -288,6 +288,28 @@ def test_render_full_image_properties(ops):
     assert_close(m[sl][None], rm, "mask slice vs oracle")
 
 
+def test_render_early_termination_is_bounded_and_opt_in(ops):
+    """early_stop_eps > 0 skips fine tiles behind (coarse) transmittance < eps: the image moves by a few eps; eps = 0 is exact.
+    An opaque slab is forced by scaling the density head's bias so that rays do terminate."""
+    sc = Scene(64, 1, "center_fixed", 20)
+    sc.raw["mlp"]["layers.2.bias"] = sc.raw["mlp"]["layers.2.bias"].clone()
+    sc.raw["mlp"]["layers.2.bias"][0, 3, 0] = 3.0            # large positive sigma everywhere inside the cubes
+    ds = DeviceScene(sc)
+    coord = sc.raw["image_coord"]
+    exact = ds.render(coord, 48, 64, None, seed=11, debug=True, count=True)
+    bins = exact.taps["bins"]
+    fast = ds.render(coord, 48, 64, _cpu(bins), early_stop_eps=1e-3, count=True)
+    again = ds.render(coord, 48, 64, _cpu(bins), early_stop_eps=0.0)
+    assert torch.equal(again.mask, exact.mask)
+    skipped = int(_cpu(fast.counters)[4])
+    assert skipped > 0 and int(_cpu(exact.counters)[4]) == 0
+    # the coarse pass only estimates the fine transmittance (mid-point samples, other sample positions): the bound
+    # is a small multiple of eps, not eps itself
+    assert float((fast.mask - exact.mask).abs().max()) < 2e-2
+    assert float((fast.color - exact.color).abs().max()) < 2e-2
+    assert int(_cpu(fast.counters)[0]) < int(_cpu(exact.counters)[0])      # fewer (part, point) pairs gathered
+
+
 def test_render_rejects_unsupported(ops):
     sc = Scene(32, 1, "center_fixed", 20)
     ds = DeviceScene(sc)

@@ -56,3 +56,31 @@ def test_split_range_properties():
     with pytest.raises(ValueError):
         sharding.split_range(4, 2, 2)
     assert list(sharding.frames_for_rank(10, 1, 4)) == [3, 4, 5]
+
+
+def _grad_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from enarf_gan_amd import sharding
+    torch.manual_seed(0)
+    ps = [torch.nn.Parameter(torch.zeros(3, 5)), torch.nn.Parameter(torch.zeros(7)), torch.nn.Parameter(torch.zeros(2, 2)),
+          torch.nn.Parameter(torch.zeros(4), requires_grad=False)]
+    ps[0].grad = torch.full((3, 5), float(rank + 1))
+    ps[1].grad = torch.arange(7.0) * (rank + 1)
+    # ps[2] has no gradient on any rank -> zeros
+    n = sharding.all_reduce_gradients(ps, bucket_bytes=64)        # 60 B + 28 B > 64 B -> two buckets, + one for ps[2]
+    ok = torch.allclose(ps[0].grad, torch.full((3, 5), 1.5)) and torch.allclose(ps[1].grad, torch.arange(7.0) * 1.5) \
+        and torch.equal(ps[2].grad, torch.zeros(2, 2)) and ps[3].grad is None and n == 2
+    if rank == 0:
+        ret["ok"], ret["n"] = bool(ok), n
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_bucketed_gradient_all_reduce():
+    mgr = mp.get_context("spawn").Manager()
+    ret = mgr.dict()
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_grad_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert ret["ok"], dict(ret)
