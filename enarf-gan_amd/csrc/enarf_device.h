@@ -86,6 +86,52 @@ __device__ __forceinline__ float wave_scan_incl(float v, int lane) {
     return v;
 }
 
+// ---- "wave vectors": SPL values per lane = SPL * 64 elements along a ray, element e = 64 s + lane --------------------
+template <int SPL>
+__device__ __forceinline__ void wv_scan_incl(float v[SPL], int lane) {
+    float carry = 0.0f;
+#pragma unroll
+    for (int s = 0; s < SPL; ++s) {
+        v[s] = wave_scan_incl(v[s], lane) + carry;
+        carry = __shfl(v[s], 63);
+    }
+}
+template <int SPL>
+__device__ __forceinline__ float wv_get(const float v[SPL], int idx) {      // idx may differ per lane
+    float r = __shfl(v[0], idx & 63);
+    if (SPL == 2) {
+        const float r1 = __shfl(v[SPL - 1], idx & 63);
+        r = (idx >= 64) ? r1 : r;
+    }
+    return r;
+}
+template <int SPL>
+__device__ __forceinline__ void wv_prev(const float v[SPL], float out[SPL], int lane) {    // out[e] = v[e-1], out[0] = 0
+    float carry = 0.0f;
+#pragma unroll
+    for (int s = 0; s < SPL; ++s) {
+        const float up = __shfl_up(v[s], 1);
+        out[s] = (lane == 0) ? carry : up;
+        carry = __shfl(v[s], 63);
+    }
+}
+template <int SPL>
+__device__ __forceinline__ void wv_next(const float v[SPL], float out[SPL], int lane) {    // out[e] = v[e+1] (last: 0)
+#pragma unroll
+    for (int s = 0; s < SPL; ++s) {
+        const float dn = __shfl_down(v[s], 1);
+        const float nxt = (s + 1 < SPL) ? __shfl(v[(s + 1 < SPL) ? s + 1 : s], 0) : 0.0f;
+        out[s] = (lane == 63) ? nxt : dn;
+    }
+}
+template <int SPL>
+__device__ __forceinline__ float wv_sum(const float v[SPL]) {
+    float t = 0.0f;
+#pragma unroll
+    for (int s = 0; s < SPL; ++s) t += v[s];
+    return wave_sum(t);
+}
+
 // bijective XCD-aware remap: workgroups that the dispatcher deals round-robin to one XCD get a
 // contiguous range of logical tiles, so neighbouring ray tiles share that XCD's L2.
 __device__ __forceinline__ int xcd_remap(int orig, int nwg) {

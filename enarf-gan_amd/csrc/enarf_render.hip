@@ -386,20 +386,22 @@ __global__ __launch_bounds__(256) void ray_setup_kernel(const enarf_render_args 
     }
 }
 
-// scratch layout (floats) of the render kernel
-// (floats 0..31 and 100..111 are free)
-constexpr int SC_BTAB = 32;      // Nc + 1 bin edges (<= 65)
-constexpr int SC_CAND = 112;     // 4 waves x 32 ints
-constexpr int SC_CH = 240;       // coarse: sigma head [64]
-constexpr int SC_CBITS = 304;    // coarse: bits [64]
-constexpr int SC_CWMAX = 368;    // coarse: wmax [64]
-constexpr int SC_FH = 432;       // fine: head [4][64]
-constexpr int SC_FBITS = 688;    // fine: bits [64]
-constexpr int SC_FWMAX = 752;    // fine: wmax [64]
-constexpr int SC_QUEUE = 816;    // 2 ray ids (current / prefetched)
+// scratch layout (floats) of the render kernel; up to kMaxSamples samples per pass
+constexpr int kMaxSamples = 128;
+constexpr int SC_BTAB = 0;        // Nc + 1 bin edges (<= 129)
+constexpr int SC_CAND = 136;      // 4 waves x 32 ints
+constexpr int SC_CH = 264;        // coarse: sigma head [128]
+constexpr int SC_CBITS = 392;     // coarse: bits [128]
+constexpr int SC_CWMAX = 520;     // coarse: wmax [128]
+constexpr int SC_FH = 648;        // fine: head [4][128]
+constexpr int SC_FBITS = 1160;    // fine: bits [128]
+constexpr int SC_FWMAX = 1288;    // fine: wmax [128]
+constexpr int SC_QUEUE = 1416;    // 2 ray ids (current / prefetched)
 static_assert(SC_QUEUE + 2 <= kScratchFloats, "scratch overflow");
 
-template <int MODE>
+// SPL = samples per lane in the lane = sample stages: 1 for Nc, Nf <= 64, 2 up to 128 (each wave then loops over two
+// 16-sample tiles per pass)
+template <int MODE, int SPL>
 __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kernel(const enarf_render_args a, int ablate) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -472,10 +474,12 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
         const float sx = exact_mul(dmin, dx), sy = exact_mul(dmin, dy), sz = exact_mul(dmin, dz);
         const float ex = exact_mul(dmax, dx), ey = exact_mul(dmax, dy), ez = exact_mul(dmax, dz);
 
-        // ---- S1: coarse pass, wave w owns bins [w Tc, (w+1) Tc)  (rendering.py:119-131, :172)
-        {
-            const int i = wave * Tc + j4;
-            const bool active = (j4 < Tc) && (i < Nc);
+        // ---- S1: coarse pass, wave w owns bins [w Tc, (w+1) Tc), 16 at a time  (rendering.py:119-131, :172)
+#pragma unroll
+        for (int u = 0; u < SPL; ++u) {
+            if (16 * u >= Tc) break;
+            const int jj = 16 * u + j4, i = wave * Tc + jj;
+            const bool active = (jj < Tc) && (i < Nc);
             const int ci = min(i, Nc - 1);
             const float b0 = l_btab[ci], b1 = l_btab[ci + 1];
             const float px = exact_mid(exact_lerp(sx, ex, b1), exact_lerp(sx, ex, b0));
@@ -486,118 +490,169 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
             uint32_t bits;
             float wmax;
             query_tile<MODE, false>(S, l_cand, ncand, px, py, pz, active, lane, o, ran, bits, wmax, nodbg, n_pairs, n_tiles, &n_rounds);
-            if (lane < Tc && wave * Tc + lane < Nc) l_ch[wave * Tc + lane] = o[3];
+            const int jm = 16 * u + lane;                       // MFMA layout: lanes < 16 hold the head of sample jm
+            if (lane < 16 && jm < Tc && wave * Tc + jm < Nc) l_ch[wave * Tc + jm] = o[3];
             if (active && (lane & 3) == 0) { l_cbits[i] = bits; l_cwmax[i] = wmax; }
         }
         __syncthreads();
         const long long next_ray = queue_entry((unsigned int)l_q[qslot ^ 1], my_q);
         qslot ^= 1;
 
-        // ---- S2 (every wave, lane = sample): weights (rendering.py:180-184), smoothing (:187-190), bins (:192-197)
-        float bin;
-        bool skip_tile;
+        // ---- S2 (every wave, element e = 64 s + lane): weights (rendering.py:180-184), smoothing (:187-190), bins (:192-197)
+        float bin[SPL];
+        bool skip_tile[SPL];
         {
-            const bool active = lane < Nc;
-            const int ci = min(lane, Nc - 1);
-            const float den = active ? density_head(l_ch[ci], l_cbits[ci], l_cwmax[ci], S.mult_w, P) : 0.0f;
-            if (a.dbg_coarse_density && active && wave == 0) a.dbg_coarse_density[((size_t)b * n + ray) * Nc + lane] = den;
-            const float b0 = l_btab[ci], b1 = l_btab[ci + 1];
-            const float delta = exact_lerp(dmin, dmax, b1) - exact_lerp(dmin, dmax, b0);
-            const float dd = active ? den * delta * a.render_scale : 0.0f;
-            const float cs = wave_scan_incl(dd, lane);
-            const float T = expf(-(cs - dd));
-            const float wgt = active ? T * (1.0f - expf(-dd)) : 0.0f;
-            float wl = __shfl_up(wgt, 1), wr = __shfl_down(wgt, 1);
-            if (lane == 0) wl = 0.0f;
-            if (lane >= Nc - 1) wr = 0.0f;
-            const float ws = active ? (fmaxf(wl, wgt) + fmaxf(wgt, wr)) / 2.0f + 0.01f : 0.0f;
-            if (a.bins) {
-                bin = a.bins[((size_t)b * n + ray) * Nf + min(lane, Nf - 1)];
+            float dd[SPL], cs[SPL], T[SPL], wgt[SPL], ws[SPL], wl[SPL], wr[SPL];
+#pragma unroll
+            for (int s = 0; s < SPL; ++s) {
+                const int e = 64 * s + lane;
+                const bool active = e < Nc;
+                const int ci = min(e, Nc - 1);
+                const float den = active ? density_head(l_ch[ci], l_cbits[ci], l_cwmax[ci], S.mult_w, P) : 0.0f;
+                if (a.dbg_coarse_density && active && wave == 0) a.dbg_coarse_density[((size_t)b * n + ray) * Nc + e] = den;
+                const float b0 = l_btab[ci], b1 = l_btab[ci + 1];
+                const float delta = exact_lerp(dmin, dmax, b1) - exact_lerp(dmin, dmax, b0);
+                dd[s] = active ? den * delta * a.render_scale : 0.0f;
+                cs[s] = dd[s];
+            }
+            wv_scan_incl<SPL>(cs, lane);
+#pragma unroll
+            for (int s = 0; s < SPL; ++s) {
+                T[s] = expf(-(cs[s] - dd[s]));
+                wgt[s] = (64 * s + lane < Nc) ? T[s] * (1.0f - expf(-dd[s])) : 0.0f;
+            }
+            wv_prev<SPL>(wgt, wl, lane);
+            wv_next<SPL>(wgt, wr, lane);
+#pragma unroll
+            for (int s = 0; s < SPL; ++s) {
+                const int e = 64 * s + lane;
+                if (e >= Nc - 1) wr[s] = 0.0f;
+                ws[s] = (e < Nc) ? (fmaxf(wl[s], wgt[s]) + fmaxf(wgt[s], wr[s])) / 2.0f + 0.01f : 0.0f;
+            }
+            if (ablate & 8) {
+#pragma unroll
+                for (int s = 0; s < SPL; ++s) bin[s] = (float)(64 * s + lane) / (float)Nf;
+            } else if (a.bins) {
+#pragma unroll
+                for (int s = 0; s < SPL; ++s) bin[s] = a.bins[((size_t)b * n + ray) * Nf + min(64 * s + lane, Nf - 1)];
             } else {
                 // Importance samples = Nf iid draws from the piecewise-constant pdf, sorted (rendering.py:192-197).
                 // Sorted uniforms come directly from exponential spacings (u_(i) = E_1+..+E_i / E_1+..+E_{Nf+1}),
                 // each is pushed through the inverse CDF (monotone, so the bins come out sorted): bin index by
                 // binary search, position inside the bin by the leftover - the same law as multinomial + U/Nc.
-                const float cdf = wave_scan_incl(ws, lane);
-                const float total = __shfl(cdf, Nc - 1);
-                uint32_t rnd[4];
-                philox4x32(rid, 0u, (uint32_t)lane, 0x454E4152u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), rnd);
-                const float e = (lane < Nf) ? -__logf(1.0f - u32_to_unit(rnd[0])) : 0.0f;
-                const float esum = wave_scan_incl(e, lane);
-                const float etot = __shfl(esum, 63) - __logf(1.0f - u32_to_unit(__shfl((int)rnd[1], 0)));
-                const float target = fminf(esum / etot, 0.99999994f) * total;
-                int lo = 0, hi = Nc - 1;   // smallest i with cdf[i] > target
+                float cdf[SPL], esum[SPL];
+                uint32_t r1_first = 0;
 #pragma unroll
-                for (int it = 0; it < 6; ++it) {
-                    const int mid = (lo + hi) >> 1;
-                    const float c = __shfl(cdf, mid);
-                    if (lo < hi) { if (c > target) hi = mid; else lo = mid + 1; }
+                for (int s = 0; s < SPL; ++s) {
+                    cdf[s] = ws[s];
+                    uint32_t rnd[4];
+                    philox4x32(rid, 0u, (uint32_t)(64 * s + lane), 0x454E4152u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), rnd);
+                    esum[s] = (64 * s + lane < Nf) ? -__logf(1.0f - u32_to_unit(rnd[0])) : 0.0f;
+                    if (s == 0) r1_first = rnd[1];
                 }
-                const float c_hi = __shfl(cdf, lo), c_lo = __shfl(cdf, max(lo - 1, 0));
-                const float below = (lo > 0) ? c_lo : 0.0f;
-                const float frac = fminf(fmaxf((target - below) / (c_hi - below), 0.0f), 0.99999994f);
-                bin = (lane < Nf) ? ((float)lo + frac) / (float)Nc : 3.0e38f;
+                wv_scan_incl<SPL>(cdf, lane);
+                wv_scan_incl<SPL>(esum, lane);
+                const float total = wv_get<SPL>(cdf, Nc - 1);
+                const float etot = __shfl(esum[SPL - 1], 63) - __logf(1.0f - u32_to_unit((uint32_t)__shfl((int)r1_first, 0)));
+#pragma unroll
+                for (int s = 0; s < SPL; ++s) {
+                    const float target = fminf(esum[s] / etot, 0.99999994f) * total;
+                    int lo = 0, hi = Nc - 1;   // smallest i with cdf[i] > target
+#pragma unroll
+                    for (int it = 0; it < 5 + SPL; ++it) {
+                        const int mid = (lo + hi) >> 1;
+                        const float c = wv_get<SPL>(cdf, mid);
+                        if (lo < hi) { if (c > target) hi = mid; else lo = mid + 1; }
+                    }
+                    const float c_hi = wv_get<SPL>(cdf, lo), c_lo = wv_get<SPL>(cdf, max(lo - 1, 0));
+                    const float below = (lo > 0) ? c_lo : 0.0f;
+                    const float frac = fminf(fmaxf((target - below) / (c_hi - below), 0.0f), 0.99999994f);
+                    bin[s] = (64 * s + lane < Nf) ? ((float)lo + frac) / (float)Nc : 3.0e38f;
+                }
             }
-            if (a.dbg_bins && lane < Nf && wave == 0) a.dbg_bins[((size_t)b * n + ray) * Nf + lane] = bin;
-            // early ray termination (opt-in, early_stop_eps > 0): transmittance in front of this wave's first fine
-            // sample, read off the coarse pass (T before coarse bin j = exp(-(cs_j - dd_j))). Once it is below eps every
+            if (a.dbg_bins && wave == 0) {
+#pragma unroll
+                for (int s = 0; s < SPL; ++s)
+                    if (64 * s + lane < Nf) a.dbg_bins[((size_t)b * n + ray) * Nf + 64 * s + lane] = bin[s];
+            }
+            // early ray termination (opt-in, early_stop_eps > 0): transmittance in front of the first fine sample of
+            // each of this wave's tiles, read off the coarse pass (T before coarse bin j). Once it is below eps every
             // sample of the tile weighs < eps: the tile's gathers and MLP are skipped (its densities count as 0).
-            skip_tile = false;
-            if (a.early_stop_eps > 0.0f) {
-                const float b_first = __shfl(bin, min(wave * Tf, Nf - 1));
-                const int jbin = min(max((int)(b_first * (float)Nc), 0), Nc - 1);
-                const float T_first = __shfl(T, jbin);
-                skip_tile = T_first < a.early_stop_eps;
+#pragma unroll
+            for (int u = 0; u < SPL; ++u) {
+                skip_tile[u] = false;
+                if (a.early_stop_eps > 0.0f) {
+                    const float b_first = wv_get<SPL>(bin, min(wave * Tf + 16 * u, Nf - 1));
+                    const int jbin = min(max((int)(b_first * (float)Nc), 0), Nc - 1);
+                    skip_tile[u] = wv_get<SPL>(T, jbin) < a.early_stop_eps;
+                }
             }
         }
 
         // ---- S3: fine pass, wave w owns samples [w Tf, (w+1) Tf); the last sample only closes the last interval
-        {
-            const int i = wave * Tf + j4;
-            const bool active = (j4 < Tf) && (i < (dbgq ? Nf : Nf - 1)) && !skip_tile;
-            const float bi = __shfl(bin, min(i, Nf - 1));
+#pragma unroll
+        for (int u = 0; u < SPL; ++u) {
+            if (16 * u >= Tf) break;
+            const int jj = 16 * u + j4, i = wave * Tf + jj;
+            const bool active = (jj < Tf) && (i < (dbgq ? Nf : Nf - 1)) && !skip_tile[u];
+            const float bi = wv_get<SPL>(bin, min(i, Nf - 1));
             const float px = exact_lerp(sx, ex, bi), py = exact_lerp(sy, ey, bi), pz = exact_lerp(sz, ez, bi);
             f32x4 o;
             bool ran;
             uint32_t bits;
             float wmax;
             query_tile<MODE, false>(S, l_cand, ncand, px, py, pz, active, lane, o, ran, bits, wmax, nodbg, n_pairs, n_tiles, &n_rounds);
-            if (lane < Tf && wave * Tf + lane < Nf) {
-                const int io = wave * Tf + lane;
-                l_fh[io] = o[0]; l_fh[64 + io] = o[1]; l_fh[128 + io] = o[2]; l_fh[192 + io] = o[3];
+            const int jm = 16 * u + lane;
+            if (lane < 16 && jm < Tf && wave * Tf + jm < Nf) {
+                const int io = wave * Tf + jm;
+                l_fh[io] = o[0]; l_fh[kMaxSamples + io] = o[1]; l_fh[2 * kMaxSamples + io] = o[2]; l_fh[3 * kMaxSamples + io] = o[3];
             }
-            if ((j4 < Tf) && (i < Nf) && (lane & 3) == 0) { l_fbits[i] = active ? bits : 0u; l_fwmax[i] = wmax; }
-            if (skip_tile && lane == 0) n_skipped += 1;
+            if ((jj < Tf) && (i < Nf) && (lane & 3) == 0) { l_fbits[i] = active ? bits : 0u; l_fwmax[i] = wmax; }
+            if (skip_tile[u] && lane == 0) n_skipped += 1;
         }
         __syncthreads();
 
-        // ---- S4 (wave 0, lane = sample): compositing (rendering.py:307-335)
+        // ---- S4 (wave 0, element e = 64 s + lane): compositing (rendering.py:307-335)
         if (wave == 0) {
-            const int ci = min(lane, Nf - 1);
-            const bool have = lane < (dbgq ? Nf : Nf - 1);
-            const uint32_t bits = l_fbits[ci];
-            const float den = have ? density_head(l_fh[192 + ci], bits, l_fwmax[ci], S.mult_w, P) : 0.0f;
-            const float cr = tanhf(l_fh[ci]), cg = tanhf(l_fh[64 + ci]), cb = tanhf(l_fh[128 + ci]);
-            const float fdepth = exact_lerp(dmin, dmax, bin);
-            if (dbgq && lane < Nf) {
-                const size_t o = ((size_t)b * n + ray) * Nf + lane;
-                a.dbg_fine_density[o] = den;
-                if (a.dbg_fine_valid) a.dbg_fine_valid[o] = bits;
-                if (a.dbg_fine_color) {
-                    a.dbg_fine_color[(((size_t)b * 3 + 0) * n + ray) * Nf + lane] = cr;
-                    a.dbg_fine_color[(((size_t)b * 3 + 1) * n + ray) * Nf + lane] = cg;
-                    a.dbg_fine_color[(((size_t)b * 3 + 2) * n + ray) * Nf + lane] = cb;
+            float fdepth[SPL], dnext[SPL], den[SPL], cr[SPL], cg[SPL], cb[SPL], dd[SPL], cs[SPL];
+#pragma unroll
+            for (int s = 0; s < SPL; ++s) {
+                const int e = 64 * s + lane;
+                const int ci = min(e, Nf - 1);
+                const bool have = e < (dbgq ? Nf : Nf - 1);
+                const uint32_t bits = l_fbits[ci];
+                den[s] = have ? density_head(l_fh[3 * kMaxSamples + ci], bits, l_fwmax[ci], S.mult_w, P) : 0.0f;
+                cr[s] = tanhf(l_fh[ci]); cg[s] = tanhf(l_fh[kMaxSamples + ci]); cb[s] = tanhf(l_fh[2 * kMaxSamples + ci]);
+                fdepth[s] = exact_lerp(dmin, dmax, bin[s]);
+                if (dbgq && e < Nf) {
+                    const size_t o = ((size_t)b * n + ray) * Nf + e;
+                    a.dbg_fine_density[o] = den[s];
+                    if (a.dbg_fine_valid) a.dbg_fine_valid[o] = bits;
+                    if (a.dbg_fine_color) {
+                        a.dbg_fine_color[(((size_t)b * 3 + 0) * n + ray) * Nf + e] = cr[s];
+                        a.dbg_fine_color[(((size_t)b * 3 + 1) * n + ray) * Nf + e] = cg[s];
+                        a.dbg_fine_color[(((size_t)b * 3 + 2) * n + ray) * Nf + e] = cb[s];
+                    }
                 }
             }
-            const bool seg = lane < Nf - 1;
-            const float dnext = __shfl_down(fdepth, 1);
-            const float dd = seg ? den * (dnext - fdepth) * a.render_scale : 0.0f;
-            const float cs = wave_scan_incl(dd, lane);
-            const float T = expf(-(cs - dd));
-            const float wgt = seg ? T * (1.0f - expf(-dd)) : 0.0f;
-            const float o_r = wave_sum(wgt * cr), o_g = wave_sum(wgt * cg), o_b = wave_sum(wgt * cb);
-            const float o_m = wave_sum(wgt);
-            const float o_d = wave_sum(seg ? (wgt * 1.0f) / fdepth : 0.0f);
+            wv_next<SPL>(fdepth, dnext, lane);
+#pragma unroll
+            for (int s = 0; s < SPL; ++s) {
+                dd[s] = (64 * s + lane < Nf - 1) ? den[s] * (dnext[s] - fdepth[s]) * a.render_scale : 0.0f;
+                cs[s] = dd[s];
+            }
+            wv_scan_incl<SPL>(cs, lane);
+            float wgt[SPL], vr[SPL], vg[SPL], vb[SPL], vd[SPL];
+#pragma unroll
+            for (int s = 0; s < SPL; ++s) {
+                const bool seg = 64 * s + lane < Nf - 1;
+                const float T = expf(-(cs[s] - dd[s]));
+                wgt[s] = seg ? T * (1.0f - expf(-dd[s])) : 0.0f;
+                vr[s] = wgt[s] * cr[s]; vg[s] = wgt[s] * cg[s]; vb[s] = wgt[s] * cb[s];
+                vd[s] = seg ? (wgt[s] * 1.0f) / fdepth[s] : 0.0f;
+            }
+            const float o_r = wv_sum<SPL>(vr), o_g = wv_sum<SPL>(vg), o_b = wv_sum<SPL>(vb);
+            const float o_m = wv_sum<SPL>(wgt), o_d = wv_sum<SPL>(vd);
             if (lane == 0) {
                 a.color[((size_t)b * 3 + 0) * n + ray] = o_r;
                 a.color[((size_t)b * 3 + 1) * n + ray] = o_g;
@@ -605,8 +660,12 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
                 a.mask[(size_t)b * n + ray] = o_m;
                 a.disparity[(size_t)b * n + ray] = o_d;
             }
-            if (a.fine_weights && seg) a.fine_weights[((size_t)b * n + ray) * (Nf - 1) + lane] = wgt;
-            if (a.fine_depth && lane < Nf) a.fine_depth[((size_t)b * n + ray) * Nf + lane] = fdepth;
+#pragma unroll
+            for (int s = 0; s < SPL; ++s) {
+                const int e = 64 * s + lane;
+                if (a.fine_weights && e < Nf - 1) a.fine_weights[((size_t)b * n + ray) * (Nf - 1) + e] = wgt[s];
+                if (a.fine_depth && e < Nf) a.fine_depth[((size_t)b * n + ray) * Nf + e] = fdepth[s];
+            }
         }
         // no barrier needed here: coarse arrays are rewritten in S1' (after this ray's S3 barrier, which follows every
         // wave's S2 reads), fine arrays in S3' (after the S1' barrier, which wave 0 reaches only after this S4).
@@ -722,7 +781,7 @@ int device_cus() {
 }
 }  // namespace enarf
 
-template <int MODE>
+template <int MODE, int SPL>
 static int launch_render(const enarf_render_args &a, hipStream_t st) {
     // persistent grid: as many workgroups as stay resident (3 per CU at <= 168 VGPRs and ~37 KB LDS), never more
     // than there are rays
@@ -736,7 +795,7 @@ static int launch_render(const enarf_render_args &a, hipStream_t st) {
     const size_t lds = (size_t)lds_total_floats<MODE>(a.P) * 4;
     const char *ab = getenv("ENARF_ABLATE");      // diagnosis only: 1 skip feature gathers, 2 skip mask planes, 4 skip MLP
     if (int rc = launch_ray_setup(a, st)) return rc;
-    hipLaunchKernelGGL(render_kernel<MODE>, dim3((unsigned)wgs), dim3(256), lds, st, a, ab ? atoi(ab) : 0);
+    hipLaunchKernelGGL((render_kernel<MODE, SPL>), dim3((unsigned)wgs), dim3(256), lds, st, a, ab ? atoi(ab) : 0);
     return host::check_launch("enarf_render_fwd");
 }
 
@@ -754,18 +813,19 @@ extern "C" int enarf_render_fwd(const enarf_render_args *args, enarf_stream_t st
     if (a.n <= 0 || !a.image_coord || !a.inv_intrinsics || !a.color || !a.mask || !a.disparity)
         return host::fail(ENARF_ERR_ARG, "enarf_render_fwd: bad n or null ray/output pointer");
     if (a.Nc < 2 || a.Nf < 2) return host::fail(ENARF_ERR_ARG, "enarf_render_fwd: Nc and Nf must be >= 2 (got %d, %d)", a.Nc, a.Nf);
-    if (a.Nc > 64 || a.Nf > 64)
-        return host::fail(ENARF_ERR_UNSUPPORTED, "enarf_render_fwd: Nc=%d / Nf=%d: more than 64 samples per pass is not implemented "
-                                                 "(one lane per sample)", a.Nc, a.Nf);
+    if (a.Nc > kMaxSamples || a.Nf > kMaxSamples)
+        return host::fail(ENARF_ERR_UNSUPPORTED, "enarf_render_fwd: Nc=%d / Nf=%d: more than %d samples per pass is not implemented",
+                          a.Nc, a.Nf, kMaxSamples);
     if (a.dbg_depth_min && (!a.dbg_depth_max || !a.dbg_ray_valid))
         return host::fail(ENARF_ERR_ARG, "enarf_render_fwd: dbg_depth_min needs dbg_depth_max and dbg_ray_valid");
     if ((long long)((a.n + 63) / 64) * a.B > 0x7FFFFFFFll || (long long)a.n * a.B > 0x7FFFFFF0ll) return host::fail(ENARF_ERR_UNSUPPORTED, "enarf_render_fwd: more than 2^31 rays in one launch");
     if (!a.workspace) return host::fail(ENARF_ERR_ARG, "enarf_render_fwd: workspace is null (enarf_render_workspace_bytes() bytes of device memory)");
     hipStream_t st = (hipStream_t)stream;
+    const bool wide = a.Nc > 64 || a.Nf > 64;      // two samples per lane in the lane = sample stages
     switch (a.mlp_mode) {
-        case ENARF_MLP_F32: return launch_render<ENARF_MLP_F32>(a, st);
-        case ENARF_MLP_BF16X3: return launch_render<ENARF_MLP_BF16X3>(a, st);
-        case ENARF_MLP_F16X3: return launch_render<ENARF_MLP_F16X3>(a, st);
-        default: return launch_render<ENARF_MLP_BF16>(a, st);
+        case ENARF_MLP_F32: return wide ? launch_render<ENARF_MLP_F32, 2>(a, st) : launch_render<ENARF_MLP_F32, 1>(a, st);
+        case ENARF_MLP_BF16X3: return wide ? launch_render<ENARF_MLP_BF16X3, 2>(a, st) : launch_render<ENARF_MLP_BF16X3, 1>(a, st);
+        case ENARF_MLP_F16X3: return wide ? launch_render<ENARF_MLP_F16X3, 2>(a, st) : launch_render<ENARF_MLP_F16X3, 1>(a, st);
+        default: return wide ? launch_render<ENARF_MLP_BF16, 2>(a, st) : launch_render<ENARF_MLP_BF16, 1>(a, st);
     }
 }

@@ -327,6 +327,10 @@ def main():
     install_placeholders()
     redirect_cuda_factories()
     torch.set_num_threads(8)
+    if "--only-c4" in sys.argv:     # BASELINE config C4's sample counts (Nc 72, Nf 96) at a small frame
+        run_render_case("render_c4s_32_b2", size=32, batch=2, Nc=72, Nf=96, origin_location="center_fixed",
+                        style_dim=256, n_keep=96, seed=25)
+        return
     if "--only-grad" in sys.argv:
         run_grad_case("grad_32_b1", size=32, batch=1, Nc=48, Nf=32, origin_location="center_fixed", style_dim=20,
                       n_rays=72, seed=31)
@@ -348,6 +352,8 @@ def main():
                   n_rays=72, seed=31)
     run_grad_case("grad_32_b2", size=32, batch=2, Nc=48, Nf=32, origin_location="center_fixed", style_dim=256,
                   n_rays=48, seed=32)
+    run_render_case("render_c4s_32_b2", size=32, batch=2, Nc=72, Nf=96, origin_location="center_fixed",
+                    style_dim=256, n_keep=96, seed=25)
 
 
 if __name__ == "__main__":

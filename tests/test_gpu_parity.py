@@ -173,7 +173,8 @@ def test_query_multiply_density_with_weight(ops):
 
 
 # --------------------------------------------------------------------------------------------- a13 render
-RENDER_CASES = ["render_c0_64_b1", "render_c1_128_b1_p23", "render_c1_128_b1_p24", "render_gan_32_b2"]
+RENDER_CASES = ["render_c0_64_b1", "render_c1_128_b1_p23", "render_c1_128_b1_p24", "render_gan_32_b2",
+                "render_c4s_32_b2"]       # the last one: BASELINE config C4's sample counts, Nc 72 / Nf 96 (> 64)
 
 
 def _render_case(name):
@@ -314,4 +315,21 @@ def test_render_rejects_unsupported(ops):
     sc = Scene(32, 1, "center_fixed", 20)
     ds = DeviceScene(sc)
     with pytest.raises(NotImplementedError):
-        ds.render(sc.raw["image_coord"], 72, 96, None)
+        ds.render(sc.raw["image_coord"], 130, 96, None)
+
+
+def test_render_wide_sample_counts_in_kernel_sampling(ops):
+    """Nc / Nf above 64 (two samples per lane): in-kernel importance sampling replayed through the oracle."""
+    sc = Scene(32, 1, "center_fixed", 20)
+    ds = DeviceScene(sc)
+    coord = sc.raw["image_coord"][..., 32 * 12:32 * 12 + 96].contiguous()
+    for (Nc, Nf) in ((72, 96), (128, 128), (48, 100), (100, 40)):
+        out = ds.render(coord, Nc, Nf, None, seed=3, debug=True, mlp_mode="f32")
+        kb = _cpu(out.taps["bins"])
+        live = _cpu(out.taps["ray_validity"])[0].bool()
+        kbl = kb[0][live]
+        assert float(kbl.min()) >= 0.0 and float(kbl.max()) < 1.0 and bool((kbl[:, 1:] >= kbl[:, :-1]).all())
+        rc, rm, rd = sc.oracle_render(coord, Nc, Nf, kb, taps=False)
+        assert_close(_cpu(out.mask), rm, f"mask Nc={Nc} Nf={Nf}")
+        assert_close(_cpu(out.color), rc, f"colour Nc={Nc} Nf={Nf}")
+        assert_close(_cpu(out.disparity), rd, f"disparity Nc={Nc} Nf={Nf}")

@@ -80,7 +80,8 @@ def test_query_matches_reference(golden_dir, name):
     _assert_close(den2, den, "density explicit vs grid_sample", 1e-5)
 
 
-RENDER_CASES = ["render_c0_64_b1", "render_c1_128_b1_p23", "render_c1_128_b1_p24", "render_gan_32_b2"]
+RENDER_CASES = ["render_c0_64_b1", "render_c1_128_b1_p23", "render_c1_128_b1_p24", "render_gan_32_b2",
+                "render_c4s_32_b2"]       # the last one: BASELINE config C4's sample counts, Nc 72 / Nf 96 (> 64)
 
 
 @pytest.mark.parametrize("name", RENDER_CASES)
