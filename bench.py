@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--early-stop-eps", type=float, default=0.0, help="opt-in early ray termination (0 = exact)")
     ap.add_argument("--cache-triplane", action="store_true",
                     help="re-lay the (constant) tri-plane once instead of every step")
+    ap.add_argument("--distinct-triplanes", action="store_true",
+                    help="GAN style: one tri-plane per frame (generated on the device) instead of one shared constant tri-plane")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=256, help="rays of the same frame timed on the host cores")
     return ap.parse_args()
@@ -98,10 +100,13 @@ def main():
     cpose, cbl = O.register_canonical_pose(sc["canonical_pose"], sc["parents"], args.origin)
     d = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in sc.items()}
     tri = sc["tri_plane"][:1].contiguous().to(dev)          # one constant tri-plane shared by the batch (DSO style)
+    if args.distinct_triplanes and B > 1:                   # per-frame tri-planes: jittered copies, made on the device
+        g = torch.Generator(device=dev).manual_seed(5)
+        tri = (tri + 0.05 * torch.randn(B, *tri.shape[1:], device=dev, generator=g)).contiguous()
     mlp = {k: v.to(dev) for k, v in sc["mlp"].items()}
     cpose_d, cbl_d = cpose.to(dev), cbl.to(dev)
     coord = d["image_coord"].reshape(B, 3, n).contiguous()
-    feat_cl = torch.empty(1, 3, 256, 256, 32, device=dev)
+    feat_cl = torch.empty(tri.shape[0], 3, 256, 256, 32, device=dev)
     parts = torch.empty(B, P, 16, device=dev)
     pack = torch.empty(B, ops.mlp_pack_bytes(), dtype=torch.uint8, device=dev)
     ops.triplane_pack(tri, feat_cl)
@@ -151,7 +156,7 @@ def main():
         rays_per_step = world * B * n
         value = rays_per_step * args.steps / elapsed
         # V*12*(C+1)*4 gathered texel bytes + each tri-plane once + outputs (+ fine side outputs)
-        alg_bytes = V * 1584 + 1 * (96 + 3 * P) * 256 * 256 * 4 + B * n * 20 + B * n * (2 * Nf - 1) * 4
+        alg_bytes = V * 1584 + tri.shape[0] * (96 + 3 * P) * 256 * 256 * 4 + B * n * 20 + B * n * (2 * Nf - 1) * 4
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -166,7 +171,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"C1: DSO-style {S}x{S} frame, Nc {Nc} + Nf {Nf} samples/ray, 24 joints -> P={P} parts "
-                                   f"({args.origin}), {B} frame/GPU/step, constant fp32 tri-plane 256^2x(96+{3 * P}), "
+                                   f"({args.origin}), {B} frame/GPU/step, {'per-frame' if tri.shape[0] > 1 else 'constant'} fp32 tri-plane 256^2x(96+{3 * P}), "
                                    f"in-kernel Philox importance sampling",
                        "mlp_arith": args.mlp_mode, "early_stop_eps": args.early_stop_eps, "triplane_relayout_in_step": not args.cache_triplane,
                        "step": "enarf_prepare + enarf_triplane_pack + enarf_render_fwd"},

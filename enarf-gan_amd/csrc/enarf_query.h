@@ -57,6 +57,29 @@ __device__ __forceinline__ void tap4(const float *__restrict__ base, const Taps 
     }
 }
 
+// same, addressed as (wave-uniform base pointer) + 32-bit byte offset per lane, so that the loads can use the
+// SGPR-base form (global_load_dwordx4 v, v_off, s[base]) instead of 64-bit per-lane address arithmetic.
+// lane_off = byte offset of this lane's 32-B chunk inside a texel plus the plane's byte offset (< 2^31 for 3 x 256^2 x 128 B).
+__device__ __forceinline__ void tap4u(const char *__restrict__ base, unsigned lane_off, const Taps &t, float s[8]) {
+    const f32x4 *p00 = reinterpret_cast<const f32x4 *>(base + (lane_off + ((unsigned)t.o00 << 7)));
+    const f32x4 *p01 = reinterpret_cast<const f32x4 *>(base + (lane_off + ((unsigned)t.o01 << 7)));
+    const f32x4 *p10 = reinterpret_cast<const f32x4 *>(base + (lane_off + ((unsigned)t.o10 << 7)));
+    const f32x4 *p11 = reinterpret_cast<const f32x4 *>(base + (lane_off + ((unsigned)t.o11 << 7)));
+    const f32x4 a0 = p00[0], a1 = p00[1], b0 = p01[0], b1 = p01[1];
+    const f32x4 c0 = p10[0], c1 = p10[1], d0 = p11[0], d1 = p11[1];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        s[c] = a0[c] * t.w00;
+        s[c] += b0[c] * t.w01;
+        s[c] += c0[c] * t.w10;
+        s[c] += d0[c] * t.w11;
+        s[4 + c] = a1[c] * t.w00;
+        s[4 + c] += b1[c] * t.w01;
+        s[4 + c] += c1[c] * t.w10;
+        s[4 + c] += d1[c] * t.w11;
+    }
+}
+
 // acc[c] += weight * sum over planes xy, yz, zx of bilinear(feature plane, canonical)  (sampling.py:79-127)
 __device__ __forceinline__ void gather_pair(const float *__restrict__ featg, int H, int W,
                                             float cx, float cy, float cz, float wgt, float acc[8]) {
@@ -396,9 +419,10 @@ __device__ __forceinline__ void query_tile(const QueryCtx &S, const int *cand_li
 #pragma unroll
     for (int c = 0; c < 8; ++c) feat[c] = 0.0f;
     wmax = 0.0f;
-    const float *featg = S.feat + 8 * g;
+    const char *featb = reinterpret_cast<const char *>(S.feat);                  // wave-uniform
     const size_t mplane = (size_t)S.H * S.W;
-    const size_t fplane = mplane * kFeat;
+    const unsigned fplane_b = (unsigned)(mplane * kFeat * sizeof(float));        // bytes per feature plane
+    const unsigned goff = (unsigned)g << 5;                                       // this lane's 32-B chunk
     uint32_t rem = b;
     while (true) {
         const uint64_t bal = __ballot(rem != 0);
@@ -429,7 +453,7 @@ __device__ __forceinline__ void query_tile(const QueryCtx &S, const int *cand_li
         float acc[8];
         {
             const Taps t0 = quad_bcast_taps<0>(t);
-            if (act && !(S.ablate & 1)) tap4(featg, t0, acc);
+            if (act && !(S.ablate & 1)) tap4u(featb, goff, t0, acc);
             else {
 #pragma unroll
                 for (int c = 0; c < 8; ++c) acc[c] = 0.0f;
@@ -440,7 +464,7 @@ __device__ __forceinline__ void query_tile(const QueryCtx &S, const int *cand_li
             const Taps t1 = quad_bcast_taps<1>(t);
             float s1[8];
             if (act && !(S.ablate & 1)) {
-                tap4(featg + fplane, t1, s1);
+                tap4u(featb, goff + fplane_b, t1, s1);
 #pragma unroll
                 for (int c = 0; c < 8; ++c) acc[c] += s1[c];
             }
@@ -450,7 +474,7 @@ __device__ __forceinline__ void query_tile(const QueryCtx &S, const int *cand_li
             const Taps t2 = quad_bcast_taps<2>(t);
             float s2[8];
             if (act && !(S.ablate & 1)) {
-                tap4(featg + 2 * fplane, t2, s2);
+                tap4u(featb, goff + 2u * fplane_b, t2, s2);
 #pragma unroll
                 for (int c = 0; c < 8; ++c) acc[c] += s2[c];
             }
@@ -465,9 +489,9 @@ __device__ __forceinline__ void query_tile(const QueryCtx &S, const int *cand_li
         const Taps t0 = quad_bcast_taps<0>(t), t1 = quad_bcast_taps<1>(t), t2 = quad_bcast_taps<2>(t);
         float s0[8], s1[8], s2[8];
         if (act && !(S.ablate & 1)) {
-            tap4(featg, t0, s0);
-            tap4(featg + fplane, t1, s1);
-            tap4(featg + 2 * fplane, t2, s2);
+            tap4u(featb, goff, t0, s0);
+            tap4u(featb, goff + fplane_b, t1, s1);
+            tap4u(featb, goff + 2u * fplane_b, t2, s2);
         } else {
 #pragma unroll
             for (int c = 0; c < 8; ++c) s0[c] = s1[c] = s2[c] = 0.0f;
