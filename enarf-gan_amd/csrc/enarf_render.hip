@@ -322,21 +322,41 @@ __global__ __launch_bounds__(256) void ray_setup_kernel(const enarf_render_args 
     uint32_t cand_all = mine | (uint32_t)quad_perm_i<0xB1>((int)mine);
     cand_all |= (uint32_t)quad_perm_i<0x4E>((int)cand_all);
 
-    // exact range test: this lane's 8 of the 32 depths x candidate parts
-    float mn = 1.0e3f, mx = -1.0e3f;
-    for (int di = g * 8; di < g * 8 + 8; ++di) {
-        const float ds = l_dtab[di];
-        const float qx = exact_mul(dx, ds), qy = exact_mul(dy, ds), qz = exact_mul(dz, ds);
-        bool inside = false;
+    // exact range test: this lane's 8 of the 32 depths x candidate parts; part outer (its frame is read from LDS
+    // once), depths inner; bit d of `in8` = some part contains depth g*8 + d
+    float qx[8], qy[8], qz[8];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+        const float ds = l_dtab[g * 8 + d];
+        qx[d] = exact_mul(dx, ds); qy[d] = exact_mul(dy, ds); qz[d] = exact_mul(dz, ds);
+    }
+    uint32_t in8 = 0;
+    {
         uint32_t m = cand_all;
         while (m) {
             const int k = __builtin_ctz(m);
             m &= m - 1;
-            float lx, ly, lz;
-            exact_local(l_parts + k * kLdsPartStride, qx, qy, qz, lx, ly, lz);
-            inside = inside || in_unit_cube_incl(lx, ly, lz);
+            float F[12];
+            const f32x4 *pf = reinterpret_cast<const f32x4 *>(l_parts + k * kLdsPartStride);
+            const f32x4 f0 = pf[0], f1 = pf[1], f2 = pf[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { F[i] = f0[i]; F[4 + i] = f1[i]; F[8 + i] = f2[i]; }
+#pragma unroll
+            for (int d = 0; d < 8; ++d) {
+                float lx, ly, lz;
+                exact_local(F, qx[d], qy[d], qz[d], lx, ly, lz);
+                if (in_unit_cube_incl(lx, ly, lz)) in8 |= 1u << d;
+            }
         }
-        if (inside) { mn = fminf(mn, ds); mx = fmaxf(mx, ds); }
+    }
+    float mn = 1.0e3f, mx = -1.0e3f;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+        if ((in8 >> d) & 1u) {
+            const float ds = l_dtab[g * 8 + d];
+            mn = fminf(mn, ds);
+            mx = fmaxf(mx, ds);
+        }
     }
     mn = fminf(mn, quad_perm_f<0xB1>(mn)); mn = fminf(mn, quad_perm_f<0x4E>(mn));
     mx = fmaxf(mx, quad_perm_f<0xB1>(mx)); mx = fmaxf(mx, quad_perm_f<0x4E>(mx));
