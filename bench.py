@@ -3,9 +3,9 @@
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched with
 torch.distributed.run, one rank per GPU. One step = one pass of the hot path over one batch of rays that
-is already resident in HBM: enarf_prepare (part frames + modulated MLP weights) -> enarf_triplane_pack
-(NCHW -> channel-last feature planes) -> enarf_render_fwd (the fused ray march, in-kernel importance
-sampling). Rank 0 prints ONE JSON line. Weak scaling: every rank renders its own frame(s); the path
+is already resident in HBM: enarf_render_step_fwd = one pre-march launch (part frames + modulated MLP weights,
+NCHW -> channel-last feature planes, ray set-up) + the fused ray march (in-kernel importance sampling); with
+--unfused the same work as enarf_prepare -> enarf_triplane_pack -> enarf_render_fwd. Rank 0 prints ONE JSON line. Weak scaling: every rank renders its own frame(s); the path
 has no exchange step, so there is no data-path collective.
 
 Workload = BASELINE.json configs[1]: 128x128 rays, Nc 48 + Nf 64 samples/ray, 24 SMPL joints (P = 23
@@ -46,6 +46,9 @@ def parse():
                     help="re-lay the (constant) tri-plane once instead of every step")
     ap.add_argument("--distinct-triplanes", action="store_true",
                     help="GAN style: one tri-plane per frame (generated on the device) instead of one shared constant tri-plane")
+    ap.add_argument("--unfused", action="store_true",
+                    help="issue prepare / re-layout / render as the three separate C-ABI calls (4 launches + memset) "
+                         "instead of enarf_render_step_fwd (2 launches + memset)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=256, help="rays of the same frame timed on the host cores")
     return ap.parse_args()
@@ -111,7 +114,15 @@ def main():
     pack = torch.empty(B, ops.mlp_pack_bytes(), dtype=torch.uint8, device=dev)
     ops.triplane_pack(tri, feat_cl)
 
+    def bound_step(seed, count=False):
+        return ops.RenderStep(d["pose_to_camera"], d["bone_length"], cbl_d, d["z_rend"], mlp, sc["parents"], args.origin,
+                              3.0, coord, d["inv_intrinsics"], cpose_d, tri, feat_cl, Nc, Nf, parts_out=parts,
+                              pack_out=pack, relayout=not args.cache_triplane, seed=seed, mlp_mode=args.mlp_mode,
+                              want_fine=True, count=count, early_stop_eps=args.early_stop_eps)
+
     def step(i, count=False):
+        if not args.unfused:
+            return bound_step(99 + i, count).run()
         ops.prepare(d["pose_to_camera"], d["bone_length"], cbl_d, d["z_rend"], mlp, sc["parents"], args.origin,
                     3.0, parts_out=parts, pack_out=pack)
         if not args.cache_triplane:
@@ -134,6 +145,13 @@ def main():
         dist.barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
+        if not args.unfused:      # same two launches as enarf_render_step_fwd(ENARF_STEP_ALL), with the march bracketed
+            st = bound_step(99)
+            st.run(ops.STEP_PRE)
+            ev0[i].record()
+            st.run(ops.STEP_MARCH)
+            ev1[i].record()
+            continue
         ops.prepare(d["pose_to_camera"], d["bone_length"], cbl_d, d["z_rend"], mlp, sc["parents"], args.origin,
                     3.0, parts_out=parts, pack_out=pack)
         if not args.cache_triplane:
@@ -174,7 +192,8 @@ def main():
                                    f"({args.origin}), {B} frame/GPU/step, {'per-frame' if tri.shape[0] > 1 else 'constant'} fp32 tri-plane 256^2x(96+{3 * P}), "
                                    f"in-kernel Philox importance sampling",
                        "mlp_arith": args.mlp_mode, "early_stop_eps": args.early_stop_eps, "triplane_relayout_in_step": not args.cache_triplane,
-                       "step": "enarf_prepare + enarf_triplane_pack + enarf_render_fwd"},
+                       "step": ("enarf_prepare + enarf_triplane_pack + enarf_render_fwd" if args.unfused else
+                                "enarf_render_step_fwd (pre-march launch: re-layout + prepare + ray set-up; then the march)")},
             "roofline": {"bound": "hbm", "kernel": "enarf::render_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes,

@@ -103,6 +103,8 @@ SIGNATURES = {
     "enarf_query_fwd": (C.c_int, [C.POINTER(QueryArgs), C.c_void_p]),
     "enarf_render_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "enarf_render_fwd": (C.c_int, [C.POINTER(RenderArgs), C.c_void_p]),
+    "enarf_render_step_fwd": (C.c_int, [C.POINTER(PrepareArgs), _f32p, _f32p, C.c_int, C.c_int, C.POINTER(RenderArgs),
+                                        C.c_int, C.c_void_p]),
     "enarf_render_bwd_rows_per_image": (C.c_longlong, [C.c_int, C.c_int]),
     "enarf_render_bwd": (C.c_int, [C.POINTER(RenderBwdArgs), C.c_void_p]),
     "enarf_prepare_bwd": (C.c_int, [C.POINTER(PrepareBwdArgs), C.c_void_p]),

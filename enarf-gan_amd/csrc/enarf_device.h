@@ -233,6 +233,23 @@ __device__ __forceinline__ float styled_act(float v) {
     return fmaxf(v, 0.2f * v) * 1.41421356237309515f;      // max(v, 0.2 v) == leaky_relu(v, 0.2)
 }
 
+// ---- NCHW -> channel-last re-layout of one (b, plane, row, 64-column) block ----------------------------------------------
+// in: (B, in_ch_total, H, W), planes p = 0..2 at channels [p*C, (p+1)*C); out: [b][p][y][x][C]; tile: C*65 floats of LDS.
+// Coalesced 256-B reads along x, contiguous 64*C*4-B writes.
+template <int C>
+__device__ __forceinline__ void pack_block(const float *__restrict__ in, float *__restrict__ out, int in_ch_total, int H,
+                                           int W, int xblk, int y, int bp, int tid, float *tile) {
+    const int xb = xblk * 64, b = bp / 3, p = bp % 3;
+    const float *src = in + (((size_t)b * in_ch_total + p * C) * H + y) * W;
+    const int x = tid & 63;
+    for (int c = tid >> 6; c < C; c += 4)
+        tile[c * 65 + x] = (xb + x < W) ? src[(size_t)c * H * W + xb + x] : 0.0f;
+    __syncthreads();
+    float *dst = out + ((((size_t)b * 3 + p) * H + y) * W + xb) * C;
+    const int nvalid = min(64, W - xb) * C;
+    for (int o = tid; o < nvalid; o += 256) dst[o] = tile[(o % C) * 65 + (o / C)];
+}
+
 // ---- bf16 helpers -------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned short f32_to_bf16_rne(float f) {
     unsigned u = __float_as_uint(f);

@@ -54,45 +54,60 @@ __device__ __forceinline__ void pack_weight_row(float *__restrict__ pf, short *_
     }
 }
 
-__global__ __launch_bounds__(256) void prepare_kernel(const PrepareParams prm) {
-    // grid = (3, B): block (layer, b) packs one layer of image b's MLP; the layer-0 block also writes the part frames
-    const enarf_prepare_args &a = prm.a;
-    const int layer = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+// part frame k of image b (pose_utils.py:129-148, rendering.py:258-260, narf.py:165): out = 16 floats
+// (R row-major 9, t x coordinate_scale 3, canonical scale, pad), exact op order
+__device__ __forceinline__ void compute_part_frame(const enarf_prepare_args &a, int b, int k, float out[16]) {
+    const int J = a.num_joints;
+    const float *pose = a.pose_to_camera + (size_t)b * J * 16;
+    float bl;
+    if (k < J - 1) {
+        const int j = k + 1, p = a.parents[j];
+        const int rs = (a.origin_location == ENARF_ORIGIN_CENTER) ? j : p;
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) out[r * 3 + c] = pose[rs * 16 + r * 4 + c];
+        for (int r = 0; r < 3; ++r) {
+#pragma clang fp contract(off)
+            out[9 + r] = ((pose[j * 16 + r * 4 + 3] + pose[p * 16 + r * 4 + 3]) / 2.0f) * a.coordinate_scale;
+        }
+        bl = a.bone_length[(size_t)b * (J - 1) + k];
+    } else {   // center+head: the head joint's own frame, bone length 1
+        const int hj = 15;
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) out[r * 3 + c] = pose[hj * 16 + r * 4 + c];
+        for (int r = 0; r < 3; ++r) out[9 + r] = exact_mul(pose[hj * 16 + r * 4 + 3], a.coordinate_scale);
+        bl = 1.0f;
+    }
+    {
+#pragma clang fp contract(off)
+        out[12] = (a.canonical_bone_length[k] / bl) / a.coordinate_scale;
+    }
+    out[13] = out[14] = out[15] = 0.0f;
+}
+// z of part k's centre (scaled), the quantity the batch-global near / far planes reduce over
+__device__ __forceinline__ float part_centre_z(const enarf_prepare_args &a, int b, int k) {
+    const int J = a.num_joints;
+    const float *pose = a.pose_to_camera + (size_t)b * J * 16;
+    if (k < J - 1) {
+#pragma clang fp contract(off)
+        const int j = k + 1, p = a.parents[j];
+        return ((pose[j * 16 + 2 * 4 + 3] + pose[p * 16 + 2 * 4 + 3]) / 2.0f) * a.coordinate_scale;
+    }
+    return exact_mul(pose[15 * 16 + 2 * 4 + 3], a.coordinate_scale);
+}
+
+constexpr int kPrepareSmemFloats = 2 * kHid + kHid * kHid;     // s_style, s_inv, s_w
+
+// block (layer, b): one layer of image b's MLP pack; the layer-0 block also writes the part frames
+__device__ __forceinline__ void prepare_block(const enarf_prepare_args &a, int layer, int b, int tid, float *smem) {
     const int J = a.num_joints;
     const int P = (a.origin_location == ENARF_ORIGIN_CENTER_HEAD) ? J : J - 1;
-    __shared__ float s_style[kHid];
-    __shared__ float s_inv[kHid];
-    __shared__ float s_w[kHid * kHid];
+    float *s_style = smem, *s_inv = smem + kHid, *s_w = smem + 2 * kHid;
 
-    // ---- part frames (pose_utils.py:129-148, rendering.py:258-260, narf.py:165)
     if (layer == 0 && a.parts && tid < P) {
-        const float *pose = a.pose_to_camera + (size_t)b * J * 16;
+        float fr[16];
+        compute_part_frame(a, b, tid, fr);
         float *out = a.parts + ((size_t)b * P + tid) * kPartStride;
-        float R[9], t[3], bl;
-        if (tid < J - 1) {
-            const int j = tid + 1, p = a.parents[j];
-            const int rs = (a.origin_location == ENARF_ORIGIN_CENTER) ? j : p;
-            for (int r = 0; r < 3; ++r)
-                for (int c = 0; c < 3; ++c) R[r * 3 + c] = pose[rs * 16 + r * 4 + c];
-            for (int r = 0; r < 3; ++r) {
-#pragma clang fp contract(off)
-                t[r] = ((pose[j * 16 + r * 4 + 3] + pose[p * 16 + r * 4 + 3]) / 2.0f) * a.coordinate_scale;
-            }
-            bl = a.bone_length[(size_t)b * (J - 1) + tid];
-        } else {   // center+head: the head joint's own frame, bone length 1
-            const int hj = 15;
-            for (int r = 0; r < 3; ++r)
-                for (int c = 0; c < 3; ++c) R[r * 3 + c] = pose[hj * 16 + r * 4 + c];
-            for (int r = 0; r < 3; ++r) t[r] = exact_mul(pose[hj * 16 + r * 4 + 3], a.coordinate_scale);
-            bl = 1.0f;
-        }
-        for (int i = 0; i < 9; ++i) out[i] = R[i];
-        for (int i = 0; i < 3; ++i) out[9 + i] = t[i];
-        {
-#pragma clang fp contract(off)
-            out[12] = (a.canonical_bone_length[tid] / bl) / a.coordinate_scale;
-        }
-        out[13] = out[14] = out[15] = 0.0f;
+        for (int i = 0; i < 16; ++i) out[i] = fr[i];
     }
 
     // ---- modulated, demodulated weights (custom_stylegan2/net.py:233-243) in MFMA operand order
@@ -127,6 +142,11 @@ __global__ __launch_bounds__(256) void prepare_kernel(const PrepareParams prm) {
     }
     __syncthreads();
     for (int e = tid; e < cout * cin; e += 256) pack_weight_row(pf, ph, layer, e / cin, e % cin, s_w[e] * s_inv[e / cin]);
+}
+
+__global__ __launch_bounds__(256) void prepare_kernel(const PrepareParams prm) {   // grid = (3, B)
+    __shared__ float smem[kPrepareSmemFloats];
+    prepare_block(prm.a, blockIdx.x, blockIdx.y, threadIdx.x, smem);
 }
 
 __global__ void mlp_unpack_kernel(const float *__restrict__ pf, float *__restrict__ dense) {
@@ -271,20 +291,36 @@ __device__ __forceinline__ bool ray_hits_part(const float *F, float dx, float dy
 // for the conservative slab tests and the 32 range-test depths (8 each) for the exact cube tests. Rays the
 // reference drops (batch 1, no cube hit: rendering.py:107-110, :337-350) get their zero outputs here and never
 // enter the march; all others are appended to the live list in blocks that keep image order.
-__global__ __launch_bounds__(256) void ray_setup_kernel(const enarf_render_args a, int blocks_per_image) {
-    __shared__ __attribute__((aligned(16))) float l_parts[ENARF_MAX_PARTS * kLdsPartStride];
-    __shared__ float l_dtab[32];
-    __shared__ float l_red[12];
-    __shared__ int l_cnt[5];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = tid & 3;
-    const int b = blockIdx.x / blocks_per_image, blk = blockIdx.x % blocks_per_image;
+constexpr int kSetupSmemFloats = ENARF_MAX_PARTS * kLdsPartStride + 32 + 12 + 8;
+
+// RAW: the part frames are computed here from the raw joint poses (same arithmetic as prepare_block, so the values
+// are bit-identical to a.parts) - lets set-up blocks run in the same launch as the prepare blocks. (`raw` stays a
+// reference to the kernel argument: taking its address would move the whole argument block to scratch.)
+template <bool RAW>
+__device__ __forceinline__ void ray_setup_block(const enarf_render_args &a, const enarf_prepare_args &raw, int b, int blk,
+                                                int tid, float *smem) {
+    float *l_parts = smem;
+    float *l_dtab = smem + ENARF_MAX_PARTS * kLdsPartStride;
+    float *l_red = l_dtab + 32;
+    int *l_cnt = reinterpret_cast<int *>(l_red + 12);
+    const int lane = tid & 63, wave = tid >> 6, g = tid & 3;
     const int P = a.P, n = a.n, Nf = a.Nf;
-    for (int i = tid; i < P * kPartStride; i += 256)
-        l_parts[(i / kPartStride) * kLdsPartStride + (i % kPartStride)] = a.parts[(size_t)b * P * kPartStride + i];
+    if constexpr (RAW) {
+        if (tid < P) {
+            float fr[16];
+            compute_part_frame(raw, b, tid, fr);
+            for (int i = 0; i < 16; ++i) l_parts[tid * kLdsPartStride + i] = fr[i];
+        }
+    } else {
+        for (int i = tid; i < P * kPartStride; i += 256)
+            l_parts[(i / kPartStride) * kLdsPartStride + (i % kPartStride)] = a.parts[(size_t)b * P * kPartStride + i];
+    }
     {   // batch-global near / far planes (rendering.py:15-17): min / max of every part centre's z
         float mn = 3.0e38f, mx = -3.0e38f;
         for (int i = tid; i < a.B * P; i += 256) {
-            const float z = a.parts[(size_t)i * kPartStride + 11];
+            float z;
+            if constexpr (RAW) z = part_centre_z(raw, i / P, i % P);
+            else z = a.parts[(size_t)i * kPartStride + 11];
             mn = fminf(mn, z);
             mx = fmaxf(mx, z);
         }
@@ -404,6 +440,46 @@ __global__ __launch_bounds__(256) void ray_setup_kernel(const enarf_render_args 
         uint32_t *list = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(a.workspace) + ws_list_off((long long)a.B * n));
         list[pos] = (uint32_t)rid;
     }
+}
+
+__global__ __launch_bounds__(256) void ray_setup_kernel(const enarf_render_args a, int blocks_per_image) {
+    __shared__ __attribute__((aligned(16))) float smem[kSetupSmemFloats];
+    enarf_prepare_args unused;   // never read with RAW = false
+    ray_setup_block<false>(a, unused, blockIdx.x / blocks_per_image, blockIdx.x % blocks_per_image, threadIdx.x, smem);
+}
+
+// ---- one launch for everything that precedes the march: tri-plane re-layout, MLP packs + part frames, ray set-up --------
+// The three jobs are independent (set-up blocks derive their part frames themselves), so their blocks run side by side
+// instead of three dependent launches back to back.
+struct PreParams {
+    enarf_prepare_args prep;
+    enarf_render_args rend;
+    const float *tri;          // NCHW tri-plane(s), or null: feat_cl is already up to date
+    float *feat_cl;
+    int tri_B, ch_total, H, W;
+    int n_pack, n_prep, bpi;   // block counts of the pack and prepare roles; set-up blocks per image
+};
+constexpr int kPreSmemFloats = (kPrepareSmemFloats > kFeat * 65) ? kPrepareSmemFloats : kFeat * 65;
+static_assert(kPreSmemFloats >= kSetupSmemFloats, "shared memory of the fused pre-march kernel");
+
+__global__ __launch_bounds__(256) void pre_march_kernel(const PreParams q) {
+    __shared__ __attribute__((aligned(16))) float smem[kPreSmemFloats];
+    int id = blockIdx.x;
+    const int tid = threadIdx.x;
+    // long-latency roles first (few blocks, serial chains), the bandwidth-bound re-layout blocks fill in behind them
+    if (id < q.n_prep) {
+        prepare_block(q.prep, id % 3, id / 3, tid, smem);
+        return;
+    }
+    id -= q.n_prep;
+    const int n_setup = q.bpi * q.rend.B;
+    if (id < n_setup) {
+        ray_setup_block<true>(q.rend, q.prep, id / q.bpi, id % q.bpi, tid, smem);
+        return;
+    }
+    id -= n_setup;
+    const int xblocks = (q.W + 63) / 64;
+    pack_block<kFeat>(q.tri, q.feat_cl, q.ch_total, q.H, q.W, id % xblocks, (id / xblocks) % q.H, id / (xblocks * q.H), tid, smem);
 }
 
 // scratch layout (floats) of the render kernel; up to kMaxSamples samples per pass
@@ -711,9 +787,7 @@ extern "C" int enarf_abi_version(void) { return ENARF_ABI_VERSION; }
 extern "C" const char *enarf_last_error(void) { return host::last_error(); }
 extern "C" size_t enarf_mlp_pack_bytes(void) { return kPackBytes; }
 
-extern "C" int enarf_prepare(const enarf_prepare_args *args, enarf_stream_t stream) {
-    if (!args) return host::fail(ENARF_ERR_ARG, "enarf_prepare: args is null");
-    const enarf_prepare_args &a = *args;
+static int check_prepare(const enarf_prepare_args &a) {
     if (a.B > 65535) return host::fail(ENARF_ERR_UNSUPPORTED, "enarf_prepare: B > 65535");
     if (a.B <= 0 || a.num_joints < 2 || a.num_joints > ENARF_MAX_JOINTS || a.style_dim <= 0)
         return host::fail(ENARF_ERR_ARG, "enarf_prepare: bad sizes (B=%d joints=%d style_dim=%d)", a.B, a.num_joints, a.style_dim);
@@ -730,6 +804,13 @@ extern "C" int enarf_prepare(const enarf_prepare_args *args, enarf_stream_t stre
     }
     for (int j = 1; j < a.num_joints; ++j)
         if (a.parents[j] < 0 || a.parents[j] >= a.num_joints) return host::fail(ENARF_ERR_ARG, "enarf_prepare: parents[%d]=%d out of range", j, a.parents[j]);
+    return 0;
+}
+
+extern "C" int enarf_prepare(const enarf_prepare_args *args, enarf_stream_t stream) {
+    if (!args) return host::fail(ENARF_ERR_ARG, "enarf_prepare: args is null");
+    const enarf_prepare_args &a = *args;
+    if (int rc = check_prepare(a)) return rc;
     PrepareParams prm;
     prm.a = a;
     hipLaunchKernelGGL(prepare_kernel, dim3(3, a.B), dim3(256), 0, (hipStream_t)stream, prm);
@@ -802,7 +883,7 @@ int device_cus() {
 }  // namespace enarf
 
 template <int MODE, int SPL>
-static int launch_render(const enarf_render_args &a, hipStream_t st) {
+static int launch_render(const enarf_render_args &a, hipStream_t st, bool with_setup) {
     // persistent grid: as many workgroups as stay resident (3 per CU at <= 168 VGPRs and ~37 KB LDS), never more
     // than there are rays
     const int num_cus = device_cus();
@@ -814,7 +895,8 @@ static int launch_render(const enarf_render_args &a, hipStream_t st) {
     if (wgs > total) wgs = total;
     const size_t lds = (size_t)lds_total_floats<MODE>(a.P) * 4;
     const char *ab = getenv("ENARF_ABLATE");      // diagnosis only: 1 skip feature gathers, 2 skip mask planes, 4 skip MLP
-    if (int rc = launch_ray_setup(a, st)) return rc;
+    if (with_setup)
+        if (int rc = launch_ray_setup(a, st)) return rc;
     hipLaunchKernelGGL((render_kernel<MODE, SPL>), dim3((unsigned)wgs), dim3(256), lds, st, a, ab ? atoi(ab) : 0);
     return host::check_launch("enarf_render_fwd");
 }
@@ -825,9 +907,7 @@ extern "C" size_t enarf_render_workspace_bytes(int B, int n) {
     return (ws_list_off(total) + (size_t)total * sizeof(uint32_t) + 63) & ~(size_t)63;
 }
 
-extern "C" int enarf_render_fwd(const enarf_render_args *args, enarf_stream_t stream) {
-    if (!args) return host::fail(ENARF_ERR_ARG, "enarf_render_fwd: args is null");
-    const enarf_render_args &a = *args;
+static int check_render(const enarf_render_args &a) {
     if (int rc = check_common("enarf_render_fwd", a.B, a.P, a.H, a.W, a.mlp_mode, a.parts, a.canonical_pose, a.feat_cl,
                               a.mask_planes, a.mlp_pack)) return rc;
     if (a.n <= 0 || !a.image_coord || !a.inv_intrinsics || !a.color || !a.mask || !a.disparity)
@@ -840,12 +920,51 @@ extern "C" int enarf_render_fwd(const enarf_render_args *args, enarf_stream_t st
         return host::fail(ENARF_ERR_ARG, "enarf_render_fwd: dbg_depth_min needs dbg_depth_max and dbg_ray_valid");
     if ((long long)((a.n + 63) / 64) * a.B > 0x7FFFFFFFll || (long long)a.n * a.B > 0x7FFFFFF0ll) return host::fail(ENARF_ERR_UNSUPPORTED, "enarf_render_fwd: more than 2^31 rays in one launch");
     if (!a.workspace) return host::fail(ENARF_ERR_ARG, "enarf_render_fwd: workspace is null (enarf_render_workspace_bytes() bytes of device memory)");
-    hipStream_t st = (hipStream_t)stream;
+    return 0;
+}
+
+static int dispatch_march(const enarf_render_args &a, hipStream_t st, bool with_setup) {
     const bool wide = a.Nc > 64 || a.Nf > 64;      // two samples per lane in the lane = sample stages
     switch (a.mlp_mode) {
-        case ENARF_MLP_F32: return wide ? launch_render<ENARF_MLP_F32, 2>(a, st) : launch_render<ENARF_MLP_F32, 1>(a, st);
-        case ENARF_MLP_BF16X3: return wide ? launch_render<ENARF_MLP_BF16X3, 2>(a, st) : launch_render<ENARF_MLP_BF16X3, 1>(a, st);
-        case ENARF_MLP_F16X3: return wide ? launch_render<ENARF_MLP_F16X3, 2>(a, st) : launch_render<ENARF_MLP_F16X3, 1>(a, st);
-        default: return wide ? launch_render<ENARF_MLP_BF16, 2>(a, st) : launch_render<ENARF_MLP_BF16, 1>(a, st);
+        case ENARF_MLP_F32: return wide ? launch_render<ENARF_MLP_F32, 2>(a, st, with_setup) : launch_render<ENARF_MLP_F32, 1>(a, st, with_setup);
+        case ENARF_MLP_BF16X3: return wide ? launch_render<ENARF_MLP_BF16X3, 2>(a, st, with_setup) : launch_render<ENARF_MLP_BF16X3, 1>(a, st, with_setup);
+        case ENARF_MLP_F16X3: return wide ? launch_render<ENARF_MLP_F16X3, 2>(a, st, with_setup) : launch_render<ENARF_MLP_F16X3, 1>(a, st, with_setup);
+        default: return wide ? launch_render<ENARF_MLP_BF16, 2>(a, st, with_setup) : launch_render<ENARF_MLP_BF16, 1>(a, st, with_setup);
     }
+}
+
+extern "C" int enarf_render_fwd(const enarf_render_args *args, enarf_stream_t stream) {
+    if (!args) return host::fail(ENARF_ERR_ARG, "enarf_render_fwd: args is null");
+    if (int rc = check_render(*args)) return rc;
+    return dispatch_march(*args, (hipStream_t)stream, true);
+}
+
+extern "C" int enarf_render_step_fwd(const enarf_prepare_args *prep, const float *tri_nchw, float *feat_cl, int tri_B,
+                                     int channels_total, const enarf_render_args *render, int phases, enarf_stream_t stream) {
+    if (!prep || !render) return host::fail(ENARF_ERR_ARG, "enarf_render_step_fwd: args is null");
+    if (int rc = check_prepare(*prep)) return rc;
+    if (int rc = check_render(*render)) return rc;
+    const enarf_prepare_args &p = *prep;
+    const enarf_render_args &r = *render;
+    const int P = (p.origin_location == ENARF_ORIGIN_CENTER_HEAD) ? p.num_joints : p.num_joints - 1;
+    if (!p.parts || !p.mlp_pack || p.parts != r.parts || p.mlp_pack != r.mlp_pack || p.B != r.B || P != r.P)
+        return host::fail(ENARF_ERR_ARG, "enarf_render_step_fwd: prepare outputs and render inputs must be the same buffers / sizes");
+    if (tri_nchw && (!feat_cl || tri_B <= 0 || channels_total < 3 * ENARF_FEAT_DIM))
+        return host::fail(ENARF_ERR_ARG, "enarf_render_step_fwd: bad tri-plane arguments");
+    if (!(phases & ENARF_STEP_ALL) || (phases & ~ENARF_STEP_ALL)) return host::fail(ENARF_ERR_ARG, "enarf_render_step_fwd: bad phases %d", phases);
+    hipStream_t st = (hipStream_t)stream;
+    if (!(phases & ENARF_STEP_PRE)) return dispatch_march(r, st, false);
+    hipError_t e = hipMemsetAsync(r.workspace, 0, 64, st);
+    if (e != hipSuccess) return host::fail((int)e, "enarf_render_step_fwd: hipMemsetAsync(workspace) failed: %s", hipGetErrorString(e));
+    PreParams q;
+    q.prep = p; q.rend = r; q.tri = tri_nchw; q.feat_cl = feat_cl; q.tri_B = tri_B; q.ch_total = channels_total;
+    q.H = r.H; q.W = r.W;
+    q.n_pack = tri_nchw ? ((r.W + 63) / 64) * r.H * tri_B * 3 : 0;
+    q.n_prep = 3 * p.B;
+    q.bpi = (r.n + 63) / 64;
+    const long long blocks = (long long)q.n_pack + q.n_prep + (long long)q.bpi * r.B;
+    if (blocks > 0x7FFFFFFFll) return host::fail(ENARF_ERR_UNSUPPORTED, "enarf_render_step_fwd: too many blocks");
+    hipLaunchKernelGGL(pre_march_kernel, dim3((unsigned)blocks), dim3(256), 0, st, q);
+    if (int rc = host::check_launch("enarf_render_step_fwd(pre-march)")) return rc;
+    return (phases & ENARF_STEP_MARCH) ? dispatch_march(r, st, false) : 0;
 }

@@ -83,16 +83,7 @@ template <int C>
 __global__ __launch_bounds__(256) void pack_kernel(const float *__restrict__ in, float *__restrict__ out,
                                                    int in_ch_total, int H, int W) {
     __shared__ float tile[C * 65];
-    const int tid = threadIdx.x;
-    const int xb = blockIdx.x * 64, y = blockIdx.y, bp = blockIdx.z, b = bp / 3, p = bp % 3;
-    const float *src = in + (((size_t)b * in_ch_total + p * C) * H + y) * W;
-    const int x = tid & 63;
-    for (int c = tid >> 6; c < C; c += 4)
-        tile[c * 65 + x] = (xb + x < W) ? src[(size_t)c * H * W + xb + x] : 0.0f;
-    __syncthreads();
-    float *dst = out + ((((size_t)b * 3 + p) * H + y) * W + xb) * C;
-    const int nvalid = min(64, W - xb) * C;
-    for (int o = tid; o < nvalid; o += 256) dst[o] = tile[(o % C) * 65 + (o / C)];
+    pack_block<C>(in, out, in_ch_total, H, W, blockIdx.x, blockIdx.y, blockIdx.z, threadIdx.x, tile);
 }
 
 // ---- direct NCHW forward: thread per point, channel loop outermost (no global read-modify-write) -------

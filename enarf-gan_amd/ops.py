@@ -96,12 +96,9 @@ def triplane_pack(tri_nchw: torch.Tensor, out: Optional[torch.Tensor] = None) ->
 
 
 # ---------------------------------------------------------------------------------------- prepare
-def prepare(pose_to_camera: torch.Tensor, bone_length: torch.Tensor, canonical_bone_length: torch.Tensor,
-            z_rend: torch.Tensor, mlp: Dict[str, torch.Tensor], parents: Sequence[int], origin_location: str,
-            coordinate_scale: float, parts_out: Optional[torch.Tensor] = None,
-            pack_out: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
-    """24 joints -> part frames (B,P,16) and the per-image MLP pack (B, pack_bytes) uint8."""
-    lib = _lib.load()
+def _prepare_args(pose_to_camera, bone_length, canonical_bone_length, z_rend, mlp, parents, origin_location,
+                  coordinate_scale, parts_out, pack_out):
+    """Validated enarf_prepare_args + the tensors its pointers borrow (kept alive by the caller)."""
     pose = _dev_f32(pose_to_camera, "pose_to_camera")
     B, J = pose.shape[0], pose.shape[1]
     P = num_parts(J, origin_location)
@@ -134,7 +131,19 @@ def prepare(pose_to_camera: torch.Tensor, bone_length: torch.Tensor, canonical_b
     if pack_out is None:
         pack_out = torch.empty(B, mlp_pack_bytes(), dtype=torch.uint8, device=pose.device)
     a.parts, a.mlp_pack = _p(parts_out), _p(pack_out)
-    rc = lib.enarf_prepare(C.byref(a), _stream(pose.device))
+    keep += [pose, bl, cbl, z]
+    return a, keep, parts_out, pack_out
+
+
+def prepare(pose_to_camera: torch.Tensor, bone_length: torch.Tensor, canonical_bone_length: torch.Tensor,
+            z_rend: torch.Tensor, mlp: Dict[str, torch.Tensor], parents: Sequence[int], origin_location: str,
+            coordinate_scale: float, parts_out: Optional[torch.Tensor] = None,
+            pack_out: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """24 joints -> part frames (B,P,16) and the per-image MLP pack (B, pack_bytes) uint8."""
+    lib = _lib.load()
+    a, _keep, parts_out, pack_out = _prepare_args(pose_to_camera, bone_length, canonical_bone_length, z_rend, mlp,
+                                                  parents, origin_location, coordinate_scale, parts_out, pack_out)
+    rc = lib.enarf_prepare(C.byref(a), _stream(parts_out.device))
     _lib.check(rc, "enarf_prepare")
     return parts_out, pack_out
 
@@ -237,6 +246,17 @@ def render_fwd(image_coord: torch.Tensor, inv_intrinsics: torch.Tensor, parts: t
     """The fused ray march. image_coord (B,1,3,n) or (B,3,n); returns color (B,3,n), mask (B,n), disparity (B,n),
     fine_weights (B,1,n,Nf-1), fine_depth (B,1,n,Nf) and, with debug=True, the parity taps."""
     lib = _lib.load()
+    a, o, _keep = _render_args(image_coord, inv_intrinsics, parts, canonical_pose, tri_nchw, feat_cl, mlp_pack, Nc, Nf,
+                               render_scale, bins, seed, mlp_mode, multiply_density_with_weight, drop_invalid_rays,
+                               want_fine, debug, count, early_stop_eps, return_bins)
+    _lib.check(lib.enarf_render_fwd(C.byref(a), _stream(o.color.device)), "enarf_render_fwd")
+    return o
+
+
+def _render_args(image_coord, inv_intrinsics, parts, canonical_pose, tri_nchw, feat_cl, mlp_pack, Nc, Nf, render_scale,
+                 bins, seed, mlp_mode, multiply_density_with_weight, drop_invalid_rays, want_fine, debug, count,
+                 early_stop_eps, return_bins):
+    """enarf_render_args with freshly allocated outputs + the tensors its pointers borrow."""
     coord = _dev_f32(image_coord, "image_coord")
     B, n = coord.shape[0], coord.shape[-1]
     coord = coord.reshape(B, 3, n)
@@ -261,7 +281,8 @@ def render_fwd(image_coord: torch.Tensor, inv_intrinsics: torch.Tensor, parts: t
     a.drop_invalid_rays = int(B == 1 if drop_invalid_rays is None else drop_invalid_rays)
     a.render_scale, a.early_stop_eps = float(render_scale), float(early_stop_eps)
     a.image_coord, a.inv_intrinsics, a.parts = _p(coord), _p(Ki), _p(parts)
-    a.canonical_pose = _p(_dev_f32(canonical_pose, "canonical_pose"))
+    cpose = _dev_f32(canonical_pose, "canonical_pose")
+    a.canonical_pose = _p(cpose)
     a.feat_cl, a.feat_batch_stride = _p(feat_cl), fstride
     a.mask_planes, a.mask_batch_stride = tri.data_ptr() + PLANE_CH * H * W * 4, mstride
     a.mlp_pack = _p(mlp_pack)
@@ -289,9 +310,50 @@ def render_fwd(image_coord: torch.Tensor, inv_intrinsics: torch.Tensor, parts: t
     if count:
         o.counters = torch.zeros(8, dtype=torch.int64, device=dev)
         a.counters = _p(o.counters)
-    a.workspace = _p(_render_workspace(dev, B, n))
-    _lib.check(lib.enarf_render_fwd(C.byref(a), _stream(dev)), "enarf_render_fwd")
-    return o
+    ws = _render_workspace(dev, B, n)
+    a.workspace = _p(ws)
+    return a, o, [coord, Ki, cpose, tri, bins, ws]
+
+
+STEP_PRE, STEP_MARCH, STEP_ALL = 1, 2, 3
+
+
+class RenderStep:
+    """One forward step bound to its arguments: `RenderStep(...).run()` = enarf_render_step_fwd (re-layout + prepare +
+    ray set-up in ONE launch, then the march). `run(STEP_PRE)` / `run(STEP_MARCH)` issue the two launches separately
+    (bench.py brackets the march with events that way)."""
+
+    def __init__(self, pose_to_camera, bone_length, canonical_bone_length, z_rend, mlp, parents, origin_location,
+                 coordinate_scale, image_coord, inv_intrinsics, canonical_pose, tri_nchw, feat_cl, Nc, Nf,
+                 parts_out=None, pack_out=None, relayout=True, render_scale=1.0, bins=None, seed=0, mlp_mode="f32",
+                 multiply_density_with_weight=False, drop_invalid_rays=None, want_fine=True, debug=False, count=False,
+                 early_stop_eps=0.0, return_bins=False):
+        self.lib = _lib.load()
+        self.pa, k1, self.parts, self.pack = _prepare_args(pose_to_camera, bone_length, canonical_bone_length, z_rend,
+                                                           mlp, parents, origin_location, coordinate_scale, parts_out,
+                                                           pack_out)
+        self.ra, self.out, k2 = _render_args(image_coord, inv_intrinsics, self.parts, canonical_pose, tri_nchw, feat_cl,
+                                             self.pack, Nc, Nf, render_scale, bins, seed, mlp_mode,
+                                             multiply_density_with_weight, drop_invalid_rays, want_fine, debug, count,
+                                             early_stop_eps, return_bins)
+        self.tri = _dev_f32(tri_nchw, "tri_plane")
+        self.feat_cl, self.relayout = feat_cl, relayout
+        if feat_cl.shape[0] != self.tri.shape[0]:
+            raise ValueError("feat_cl and tri_plane must have the same batch")
+        self._keep = k1 + k2
+
+    def run(self, phases: int = STEP_ALL) -> RenderOutputs:
+        t = self.tri
+        rc = self.lib.enarf_render_step_fwd(C.byref(self.pa), _p(t) if self.relayout else None, _p(self.feat_cl),
+                                            t.shape[0], t.shape[1], C.byref(self.ra), phases, _stream(t.device))
+        _lib.check(rc, "enarf_render_step_fwd")
+        return self.out
+
+
+def render_step_fwd(*args, **kw) -> RenderOutputs:
+    """prepare + tri-plane re-layout + render in two launches; arguments as RenderStep. Returns RenderOutputs
+    (plus .parts / .pack of the prepare stage as attributes of the RenderStep it ran: use RenderStep to keep them)."""
+    return RenderStep(*args, **kw).run()
 
 
 # ---------------------------------------------------------------------------------------- backward (SURVEY 8f rank 1)

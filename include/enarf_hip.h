@@ -205,6 +205,19 @@ typedef struct {
 size_t enarf_render_workspace_bytes(int B, int n);
 int enarf_render_fwd(const enarf_render_args *args, enarf_stream_t stream);
 
+/* The whole forward step in two launches: one "pre-march" launch whose blocks do enarf_triplane_pack,
+ * enarf_prepare and the ray set-up side by side (the three are independent: set-up blocks derive their part frames
+ * from the raw poses themselves, bit-identically), then the march. Same results as calling the three entry points
+ * in sequence. `render->parts` must be `prep->parts` and `render->mlp_pack` must be `prep->mlp_pack`.
+ * tri_nchw == NULL skips the re-layout (feat_cl of a constant tri-plane is already up to date).
+ * phases: ENARF_STEP_PRE | ENARF_STEP_MARCH; a caller that wants to time the march alone issues the two phases as two
+ * calls on the same stream (the march phase needs the pre-march phase of the same arguments before it). */
+#define ENARF_STEP_PRE 1
+#define ENARF_STEP_MARCH 2
+#define ENARF_STEP_ALL 3
+int enarf_render_step_fwd(const enarf_prepare_args *prep, const float *tri_nchw, float *feat_cl, int tri_B,
+                          int channels_total, const enarf_render_args *render, int phases, enarf_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Backward of the fused renderer: what `loss_gen.backward()` computes through render
  * (libraries/NeRF/rendering.py:283-335), the fine-pass query (models/narf.py:176-275), the StyledMLP and MyReLU's

@@ -333,3 +333,46 @@ def test_render_wide_sample_counts_in_kernel_sampling(ops):
         assert_close(_cpu(out.mask), rm, f"mask Nc={Nc} Nf={Nf}")
         assert_close(_cpu(out.color), rc, f"colour Nc={Nc} Nf={Nf}")
         assert_close(_cpu(out.disparity), rd, f"disparity Nc={Nc} Nf={Nf}")
+
+
+@pytest.mark.parametrize("name,Nc,Nf", [("render_c1_128_b1_p23", 48, 64), ("render_c1_128_b1_p24", 48, 64),
+                                         ("render_gan_32_b2", 48, 64)])
+def test_fused_step_is_bit_identical_to_separate_calls(ops, name, Nc, Nf):
+    """enarf_render_step_fwd (re-layout + prepare + ray set-up in one launch, then the march) against
+    enarf_triplane_pack -> enarf_prepare -> enarf_render_fwd on the same inputs: every output bit for bit, including
+    the part frames / MLP pack / channel-last planes the pre-march launch leaves behind."""
+    g, sc, coord, bins = _render_case(name)
+    ds = DeviceScene(sc)                               # separate calls
+    ref = ds.render(coord, Nc, Nf, bins, debug=True)
+    s, d = sc.raw, ds.dev
+    feat = torch.full_like(ds.feat_cl, float("nan"))
+    st = ops.RenderStep(s["pose_to_camera"].to(d), s["bone_length"].to(d), sc.cbl.to(d), s["z_rend"].to(d), ds.mlp,
+                        s["parents"], sc.ol, sc.cs, coord.to(d), ds.inv_K, ds.cpose, ds.tri, feat, Nc, Nf,
+                        bins=bins.to(d), debug=True)
+    out = st.run()
+    assert torch.equal(st.parts, ds.parts) and torch.equal(st.pack, ds.pack) and torch.equal(feat, ds.feat_cl)
+    for k in ("color", "mask", "disparity", "fine_weights", "fine_depth"):
+        assert torch.equal(getattr(out, k), getattr(ref, k)), k
+    for k, v in ref.taps.items():
+        assert torch.equal(out.taps[k], v), k
+    # the two phases as two calls, and a cached re-layout (tri_nchw = NULL), give the same again
+    st2 = ops.RenderStep(s["pose_to_camera"].to(d), s["bone_length"].to(d), sc.cbl.to(d), s["z_rend"].to(d), ds.mlp,
+                         s["parents"], sc.ol, sc.cs, coord.to(d), ds.inv_K, ds.cpose, ds.tri, ds.feat_cl, Nc, Nf,
+                         bins=bins.to(d), relayout=False)
+    st2.run(ops.STEP_PRE)
+    out2 = st2.run(ops.STEP_MARCH)
+    assert torch.equal(out2.color, ref.color) and torch.equal(out2.mask, ref.mask)
+
+
+def test_fused_step_rejects_mismatched_buffers(ops):
+    g, sc, coord, bins = _render_case("render_c0_64_b1")
+    ds = DeviceScene(sc)
+    s, d = sc.raw, ds.dev
+    st = ops.RenderStep(s["pose_to_camera"].to(d), s["bone_length"].to(d), sc.cbl.to(d), s["z_rend"].to(d), ds.mlp,
+                        s["parents"], sc.ol, sc.cs, coord.to(d), ds.inv_K, ds.cpose, ds.tri, ds.feat_cl, 48, 32)
+    st.ra.parts = ds.parts.data_ptr()                 # not the buffer the prepare stage writes
+    with pytest.raises(RuntimeError, match="same buffers"):
+        st.run()
+    st.ra.parts = st.parts.data_ptr()
+    with pytest.raises(RuntimeError, match="phases"):
+        st.run(0)
