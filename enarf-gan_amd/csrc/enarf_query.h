@@ -11,12 +11,26 @@
 #include "enarf_device.h"
 
 #ifndef ENARF_PLANE_SERIAL
-#define ENARF_PLANE_SERIAL 1
+#define ENARF_PLANE_SERIAL 2
 #endif
 
 namespace enarf {
 
+// ENARF_TIMERS=1 (diagnostic builds only, tools/gpu_timers.sh): per-wave cycle sums per phase, returned in counters[0..7]
+#ifndef ENARF_TIMERS
+#define ENARF_TIMERS 0
+#endif
+#if ENARF_TIMERS
+#define TMR(S, k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); (S).tmr[k] += now_ - (S).tmr_t; (S).tmr_t = now_; } while (0)
+#else
+#define TMR(S, k) do { } while (0)
+#endif
+
 struct QueryCtx {
+#if ENARF_TIMERS
+    mutable unsigned long long tmr[8];
+    mutable unsigned long long tmr_t;
+#endif
     int ablate;              // diagnosis-only switches (ENARF_ABLATE), wave-uniform; 0 in production
     const float *mlp;        // LDS: fp32 weights of the MLP pack [PK_W1, PK_B1) (mode F32), else unused
     const short *mlp_h;      // LDS: bf16 section (modes BF16X3 / BF16) or fp16 section (F16X3), else unused
@@ -77,6 +91,40 @@ __device__ __forceinline__ void tap4u(const char *__restrict__ base, unsigned la
         s[4 + c] += b1[c] * t.w01;
         s[4 + c] += c1[c] * t.w10;
         s[4 + c] += d1[c] * t.w11;
+    }
+}
+
+#ifndef ENARF_PIN
+#define ENARF_PIN 1
+#endif
+// an empty asm the eight values pass through: their computation can be neither sunk below nor hoisted above this point
+__device__ __forceinline__ void pin8(float v[8]) {
+#if ENARF_PIN
+    asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+#endif
+}
+
+// tap4u in two halves, so that the loads of one plane can be in flight while another plane is being reduced
+struct TapRegs { f32x4 a0, a1, b0, b1, c0, c1, d0, d1; };
+__device__ __forceinline__ void tap4u_issue(const char *__restrict__ base, unsigned lane_off, const Taps &t, TapRegs &r) {
+    const f32x4 *p00 = reinterpret_cast<const f32x4 *>(base + (lane_off + ((unsigned)t.o00 << 7)));
+    const f32x4 *p01 = reinterpret_cast<const f32x4 *>(base + (lane_off + ((unsigned)t.o01 << 7)));
+    const f32x4 *p10 = reinterpret_cast<const f32x4 *>(base + (lane_off + ((unsigned)t.o10 << 7)));
+    const f32x4 *p11 = reinterpret_cast<const f32x4 *>(base + (lane_off + ((unsigned)t.o11 << 7)));
+    r.a0 = p00[0]; r.a1 = p00[1]; r.b0 = p01[0]; r.b1 = p01[1];
+    r.c0 = p10[0]; r.c1 = p10[1]; r.d0 = p11[0]; r.d1 = p11[1];
+}
+__device__ __forceinline__ void tap4u_reduce(const TapRegs &r, const Taps &t, float s[8]) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        s[c] = r.a0[c] * t.w00;
+        s[c] += r.b0[c] * t.w01;
+        s[c] += r.c0[c] * t.w10;
+        s[c] += r.d0[c] * t.w11;
+        s[4 + c] = r.a1[c] * t.w00;
+        s[4 + c] += r.b1[c] * t.w01;
+        s[4 + c] += r.c1[c] * t.w10;
+        s[4 + c] += r.d1[c] * t.w11;
     }
 }
 
@@ -411,6 +459,7 @@ __device__ __forceinline__ void query_tile(const QueryCtx &S, const int *cand_li
             if (dbg.weight && !v) dbg.weight[(size_t)k * dbg.N + dbg.i] = 0.125f;   // sigmoid(0)^3 (sampling.py)
         }
     }
+    TMR(S, 1);
     uint32_t b = mine | (uint32_t)quad_perm_i<0xB1>((int)mine);   // [1,0,3,2]
     b |= (uint32_t)quad_perm_i<0x4E>((int)b);                     // [2,3,0,1]
     bits = b;
@@ -438,6 +487,51 @@ __device__ __forceinline__ void query_tile(const QueryCtx &S, const int *cand_li
         const float qx = (g == 1) ? cy : (g == 2) ? cz : cx;
         const float qy = (g == 1) ? cz : (g == 2) ? cx : cy;
         const Taps t = make_taps(qx, qy, S.H, S.W);   // fully clamped: every tap index is in-plane whatever the input
+#if ENARF_PLANE_SERIAL == 2
+        // Pipelined round: the 4 mask taps and the 16 feature loads of planes 0 and 1 are issued back to back; the
+        // part probability is formed while they are in flight; plane 2's loads go out as soon as plane 0 is reduced.
+        // Two exposed memory latencies per round (the serial form below has five: the compiler splits the mask taps
+        // in two waits and each plane waits on its own).
+        if (act) {   // quad-uniform, so the quad broadcasts below see all four lanes
+            const int gm = (g == 3) ? 0 : g;   // lane 3 repeats plane 0 (same addresses as lane 0: no extra traffic)
+            const char *maskb = reinterpret_cast<const char *>(S.mask);
+            const unsigned moff = ((unsigned)(3 * k + gm) * (unsigned)mplane) << 2;
+            const float m00 = *reinterpret_cast<const float *>(maskb + (moff + ((unsigned)t.o00 << 2)));
+            const float m01 = *reinterpret_cast<const float *>(maskb + (moff + ((unsigned)t.o01 << 2)));
+            const float m10 = *reinterpret_cast<const float *>(maskb + (moff + ((unsigned)t.o10 << 2)));
+            const float m11 = *reinterpret_cast<const float *>(maskb + (moff + ((unsigned)t.o11 << 2)));
+            TapRegs r0, r1, r2;
+            const Taps t0 = quad_bcast_taps<0>(t), t1 = quad_bcast_taps<1>(t);
+            tap4u_issue(featb, goff, t0, r0);
+            tap4u_issue(featb, goff + fplane_b, t1, r1);
+            __builtin_amdgcn_sched_barrier(0);
+            float macc = m00 * t.w00;   // part probability plane g (sampling.py:43-48, :62)
+            macc += m01 * t.w01;
+            macc += m10 * t.w10;
+            macc += m11 * t.w11;
+            const float sg = sigmoidf_(macc);
+            const float w = (quad_bcast_f<0>(sg) * quad_bcast_f<1>(sg)) * quad_bcast_f<2>(sg);
+            float acc[8], s1[8], s2[8];
+            tap4u_reduce(r0, t0, acc);
+            pin8(acc);      // keep the reduction here: IR-level sinking would otherwise hold all 24 loads' registers
+            __builtin_amdgcn_sched_barrier(0);
+            const Taps t2 = quad_bcast_taps<2>(t);
+            tap4u_issue(featb, goff + 2u * fplane_b, t2, r2);
+            __builtin_amdgcn_sched_barrier(0);
+            tap4u_reduce(r1, t1, s1);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc[c] += s1[c];
+            __builtin_amdgcn_sched_barrier(0);
+            tap4u_reduce(r2, t2, s2);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc[c] += s2[c];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) feat[c] += acc[c] * w;
+            wmax = fmaxf(wmax, w);
+            if (DBG && dbg.weight && g == 0) dbg.weight[(size_t)k * dbg.N + dbg.i] = w;
+        }
+        TMR(S, 3);
+#else
         float sg = 1.0f;
         if (act && g < 3 && !(S.ablate & 2)) {   // part probability plane g (sampling.py:43-48, :62)
             const float *mp = S.mask + (size_t)(3 * k + g) * mplane;
@@ -448,7 +542,8 @@ __device__ __forceinline__ void query_tile(const QueryCtx &S, const int *cand_li
             sg = sigmoidf_(acc);
         }
         const float w = (quad_bcast_f<0>(sg) * quad_bcast_f<1>(sg)) * quad_bcast_f<2>(sg);
-#if ENARF_PLANE_SERIAL
+        TMR(S, 2);
+#if ENARF_PLANE_SERIAL == 1
         // one plane's 8 loads in flight at a time: fewer VGPRs per wave, more waves per SIMD
         float acc[8];
         {
@@ -503,8 +598,10 @@ __device__ __forceinline__ void query_tile(const QueryCtx &S, const int *cand_li
             if (DBG && dbg.weight && g == 0) dbg.weight[(size_t)k * dbg.N + dbg.i] = w;
         }
 #endif
+#endif
         n_pairs += (unsigned)(__popcll(bal) >> 2);
         if (n_rounds) *n_rounds += 1;
+        TMR(S, 3);
     }
 
     ran = (__ballot(b != 0) != 0) && !(S.ablate & 4);
@@ -518,6 +615,7 @@ __device__ __forceinline__ void query_tile(const QueryCtx &S, const int *cand_li
     } else {
         o = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     }
+    TMR(S, 4);
 }
 
 }  // namespace enarf

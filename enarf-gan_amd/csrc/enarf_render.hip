@@ -542,6 +542,10 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
     const int j4 = lane >> 2;                              // this lane's sample within the wave's tile
     const bool dbgq = (a.dbg_fine_density != nullptr);
 
+#if ENARF_TIMERS
+    for (int k = 0; k < 8; ++k) S.tmr[k] = 0;
+    S.tmr_t = __builtin_amdgcn_s_memtime();
+#endif
     while (cur < total_live) {
         if (tid == 0) l_q[qslot ^ 1] = (int)atomicAdd(queue, 1u);   // prefetch the next entry; read after the S1 barrier
         const uint32_t rid = live_list[cur];
@@ -569,6 +573,7 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
         const int ncand = build_cand_list(l_cand, rec.cand, lane);
         const float sx = exact_mul(dmin, dx), sy = exact_mul(dmin, dy), sz = exact_mul(dmin, dz);
         const float ex = exact_mul(dmax, dx), ey = exact_mul(dmax, dy), ez = exact_mul(dmax, dz);
+        TMR(S, 0);
 
         // ---- S1: coarse pass, wave w owns bins [w Tc, (w+1) Tc), 16 at a time  (rendering.py:119-131, :172)
 #pragma unroll
@@ -590,7 +595,9 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
             if (lane < 16 && jm < Tc && wave * Tc + jm < Nc) l_ch[wave * Tc + jm] = o[3];
             if (active && (lane & 3) == 0) { l_cbits[i] = bits; l_cwmax[i] = wmax; }
         }
+        TMR(S, 4);
         __syncthreads();
+        TMR(S, 5);
         const long long next_ray = queue_entry((unsigned int)l_q[qslot ^ 1], my_q);
         qslot ^= 1;
 
@@ -685,6 +692,7 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
             }
         }
 
+        TMR(S, 6);
         // ---- S3: fine pass, wave w owns samples [w Tf, (w+1) Tf); the last sample only closes the last interval
 #pragma unroll
         for (int u = 0; u < SPL; ++u) {
@@ -706,7 +714,9 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
             if ((jj < Tf) && (i < Nf) && (lane & 3) == 0) { l_fbits[i] = active ? bits : 0u; l_fwmax[i] = wmax; }
             if (skip_tile[u] && lane == 0) n_skipped += 1;
         }
+        TMR(S, 4);
         __syncthreads();
+        TMR(S, 5);
 
         // ---- S4 (wave 0, element e = 64 s + lane): compositing (rendering.py:307-335)
         if (wave == 0) {
@@ -763,10 +773,16 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
                 if (a.fine_depth && e < Nf) a.fine_depth[((size_t)b * n + ray) * Nf + e] = fdepth[s];
             }
         }
+        TMR(S, 7);
         // no barrier needed here: coarse arrays are rewritten in S1' (after this ray's S3 barrier, which follows every
         // wave's S2 reads), fine arrays in S3' (after the S1' barrier, which wave 0 reaches only after this S4).
         cur = next_ray;
     }
+#if ENARF_TIMERS
+    if (a.counters && lane == 0)
+        for (int k = 0; k < 8; ++k) atomicAdd(&a.counters[k], S.tmr[k]);
+    return;
+#endif
     if (a.counters && lane == 0) {
         atomicAdd(&a.counters[0], (unsigned long long)n_pairs);
         atomicAdd(&a.counters[1], (unsigned long long)n_tiles);

@@ -1,0 +1,29 @@
+"""Phase breakdown of the march from a -DENARF_TIMERS=1 build (ENARF_LIB=variants/libenarf_timers.so): per-wave
+cycle sums per phase, printed as fractions of the summed wave time."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from enarf_gan_amd import ops, synth
+from oracle import enarf_oracle as O
+
+S, Nc, Nf = 128, 48, 64
+sc = synth.make_scene(S, 1, "center_fixed", 20, pose_seed=1234, shared_triplane=True)
+dev = torch.device("cuda:0")
+cpose, cbl = O.register_canonical_pose(sc["canonical_pose"], sc["parents"], "center_fixed")
+d = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in sc.items()}
+tri = sc["tri_plane"][:1].contiguous().to(dev)
+mlp = {k: v.to(dev) for k, v in sc["mlp"].items()}
+feat = ops.triplane_pack(tri)
+names = ["0 ray header", "1 pass A (candidate tests)", "2 round set-up + mask taps", "3 feature gathers + FMA",
+         "4 transpose + MLP", "5 barrier wait", "6 S2 weights/sampling", "7 S4 composite"]
+for rep in range(3):
+    st = ops.RenderStep(d["pose_to_camera"], d["bone_length"], cbl.to(dev), d["z_rend"], mlp, sc["parents"], "center_fixed",
+                        3.0, d["image_coord"].reshape(1, 3, S * S), d["inv_intrinsics"], cpose.to(dev), tri, feat, Nc, Nf,
+                        seed=99, mlp_mode=os.environ.get("MODE", "f16x3"), count=True)
+    out = st.run()
+    torch.cuda.synchronize()
+c = out.counters.cpu().double()
+tot = float(c.sum())
+for k in range(8):
+    print(f"{names[k]:32s} {float(c[k]) / tot * 100:6.2f} %   {float(c[k]):.3e} cycles")
+print("total wave-cycles", tot)
