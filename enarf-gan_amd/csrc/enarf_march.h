@@ -73,19 +73,52 @@ __device__ __forceinline__ int build_cand_list(int *list, uint32_t set, int lane
 }
 
 // ---- XCD-affine ray queues ---------------------------------------------------------------------------------------
-// The live-ray list is cut into blocks of kQBlock consecutive entries that are dealt round-robin to 8 queues, one
-// per XCD; a workgroup pulls from the queue of the XCD it runs on (HW_REG_XCC_ID). Neighbouring rays - which touch
-// neighbouring tri-plane texels - are then marched on ONE XCD and share its L2, instead of every XCD pulling the
-// whole window's footprint through its own L2. Placement only affects speed: any workgroup may serve any queue.
+// The live-ray list (image order) is cut into 8 contiguous bands of equal length, one queue per XCD; a workgroup pulls
+// from the band of the XCD it runs on (HW_REG_XCC_ID) and, when that is drained, steals from the next bands in turn.
+// Each XCD then marches its own part of the image(s): its L2 holds that part's tri-plane texels only, instead of every
+// XCD pulling the whole frame's footprint through its own L2 (8x the fabric reads, and the latency that goes with them).
+// Placement only affects speed: any workgroup may serve any band. ENARF_QUEUE_BANDS=0: blocks of kQBlock entries dealt
+// round-robin to the queues (every XCD sweeps the whole frame), no stealing needed.
+#ifndef ENARF_QUEUE_BANDS
+#define ENARF_QUEUE_BANDS 1
+#endif
 constexpr int kQBlock = 32;
 constexpr int kQueues = 8;
 __device__ __forceinline__ int xcc_id() {
     return (int)(__builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11)) & 0xF);   // HW_REG_XCC_ID[3:0]
 }
-// j-th dequeue of queue x -> index into the live list (may be >= total: then the queue is drained)
-__device__ __forceinline__ long long queue_entry(unsigned int j, int x) {
-    return ((long long)(j / kQBlock) * kQueues + x) * kQBlock + (j % kQBlock);
-}
+struct RayQueue {                 // used by one thread of the workgroup
+    unsigned int *heads;          // kQueues counters in the workspace header
+    long long total, band;
+    int q, tries;
+    __device__ __forceinline__ void init(unsigned int *wsh) {
+        heads = wsh + 2;
+        total = (long long)wsh[1];
+        band = (total + kQueues - 1) / kQueues;
+        q = xcc_id() & (kQueues - 1);
+        tries = 0;
+    }
+    // next index into the live list, or -1 once every queue is drained
+    __device__ __forceinline__ int pop() {
+#if ENARF_QUEUE_BANDS
+        while (tries < kQueues) {
+            const long long lo = (long long)q * band;
+            const long long len = (total - lo < band) ? total - lo : band;
+            if (len > 0) {
+                const unsigned int j = atomicAdd(heads + q, 1u);
+                if ((long long)j < len) return (int)(lo + j);
+            }
+            q = (q + 1) & (kQueues - 1);
+            tries += 1;
+        }
+        return -1;
+#else
+        const unsigned int j = atomicAdd(heads + q, 1u);
+        const long long e = ((long long)(j / kQBlock) * kQueues + q) * kQBlock + (j % kQBlock);
+        return e < total ? (int)e : -1;
+#endif
+    }
+};
 
 
 // host side, defined in enarf_render.hip

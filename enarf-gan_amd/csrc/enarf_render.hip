@@ -506,9 +506,8 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
     // moment the whole chip works on a window of a few image rows, whose tri-plane footprint stays in every XCD's L2.
     const int P = a.P, Nc = a.Nc, Nf = a.Nf, n = a.n;
     unsigned int *wsh = reinterpret_cast<unsigned int *>(a.workspace);
-    const long long total_live = (long long)wsh[1];
-    const int my_q = xcc_id() & (kQueues - 1);
-    unsigned int *queue = wsh + 2 + my_q;                   // this XCD's queue head
+    RayQueue rq;                                            // thread 0's view of the XCD-affine queues
+    rq.init(wsh);
     const RayRec *recs = reinterpret_cast<const RayRec *>(reinterpret_cast<const char *>(a.workspace) + ws_records_off());
     const uint32_t *live_list = reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(a.workspace) +
                                                                   ws_list_off((long long)a.B * n));
@@ -516,10 +515,10 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
     QueryCtx S;
     float *scratch = lds + (lds_total_floats<MODE>(P) - kScratchFloats);
     int *l_q = reinterpret_cast<int *>(scratch + SC_QUEUE);
-    if (tid == 0) l_q[0] = (int)atomicAdd(queue, 1u);
+    if (tid == 0) l_q[0] = rq.pop();
     __syncthreads();
-    long long cur = queue_entry((unsigned int)l_q[0], my_q);
-    if (cur >= total_live) return;            // uniform: this XCD's queue is already drained
+    int cur = l_q[0];
+    if (cur < 0) return;                      // uniform: every queue is already drained
     int b = (int)(live_list[cur] / (uint32_t)n);
     stage_common<MODE>(lds, S, scratch, reinterpret_cast<const char *>(a.mlp_pack) + (size_t)b * kPackBytes,
                        a.parts + (size_t)b * P * kPartStride, a.canonical_pose, P, tid, 256);
@@ -546,8 +545,8 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
     for (int k = 0; k < 8; ++k) S.tmr[k] = 0;
     S.tmr_t = __builtin_amdgcn_s_memtime();
 #endif
-    while (cur < total_live) {
-        if (tid == 0) l_q[qslot ^ 1] = (int)atomicAdd(queue, 1u);   // prefetch the next entry; read after the S1 barrier
+    while (cur >= 0) {
+        if (tid == 0) l_q[qslot ^ 1] = rq.pop();   // prefetch the next entry; read after the S1 barrier
         const uint32_t rid = live_list[cur];
         const int nb = (int)(rid / (uint32_t)n), ray = (int)(rid - (uint32_t)nb * (uint32_t)n);
         if (nb != b) {   // next image: restage its MLP pack and part frames (the list is in image order, so this is rare)
@@ -598,7 +597,7 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
         TMR(S, 4);
         __syncthreads();
         TMR(S, 5);
-        const long long next_ray = queue_entry((unsigned int)l_q[qslot ^ 1], my_q);
+        const int next_ray = l_q[qslot ^ 1];
         qslot ^= 1;
 
         // ---- S2 (every wave, element e = 64 s + lane): weights (rendering.py:180-184), smoothing (:187-190), bins (:192-197)

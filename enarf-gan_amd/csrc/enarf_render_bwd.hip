@@ -76,9 +76,8 @@ __global__ __launch_bounds__(256, kBwdWavesPerSimd) void render_bwd_kernel(const
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int P = a.P, Nf = a.Nf, n = a.n;
     unsigned int *wsh = reinterpret_cast<unsigned int *>(a.workspace);
-    const long long total_live = (long long)wsh[1];
-    const int my_q = xcc_id() & (kQueues - 1);
-    unsigned int *queue = wsh + 2 + my_q;
+    RayQueue rq;
+    rq.init(wsh);
     const RayRec *recs = reinterpret_cast<const RayRec *>(reinterpret_cast<const char *>(a.workspace) + ws_records_off());
     const uint32_t *live_list = reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(a.workspace) +
                                                                   ws_list_off((long long)a.B * n));
@@ -86,10 +85,10 @@ __global__ __launch_bounds__(256, kBwdWavesPerSimd) void render_bwd_kernel(const
     float *l_w = lds, *l_bias = l_w + PK_B1, *l_wt = l_bias + 144, *l_parts = l_wt + PKT_FLOATS;
     float *l_canon = l_parts + P * kLdsPartStride, *scratch = l_canon + P * kLdsCanonStride;
     int *l_q = reinterpret_cast<int *>(scratch + SB_QUEUE);
-    if (tid == 0) l_q[0] = (int)atomicAdd(queue, 1u);
+    if (tid == 0) l_q[0] = rq.pop();
     __syncthreads();
-    long long cur = queue_entry((unsigned int)l_q[0], my_q);
-    if (cur >= total_live) return;
+    int cur = l_q[0];
+    if (cur < 0) return;
     int b = -1;
     QueryCtx S;
     S.mlp = l_w; S.mlp_h = nullptr; S.bias = l_bias; S.parts = l_parts; S.canon = l_canon;
@@ -104,8 +103,8 @@ __global__ __launch_bounds__(256, kBwdWavesPerSimd) void render_bwd_kernel(const
     int qslot = 0;
     float *gfeat = nullptr, *gmask = nullptr;
 
-    while (cur < total_live) {
-        if (tid == 0) l_q[qslot ^ 1] = (int)atomicAdd(queue, 1u);
+    while (cur >= 0) {
+        if (tid == 0) l_q[qslot ^ 1] = rq.pop();
         const uint32_t rid = live_list[cur];
         const int nb = (int)(rid / (uint32_t)n), ray = (int)(rid - (uint32_t)nb * (uint32_t)n);
         if (nb != b) {   // (re)stage the image's weights (forward + transposed), biases and frames
@@ -218,7 +217,7 @@ __global__ __launch_bounds__(256, kBwdWavesPerSimd) void render_bwd_kernel(const
         }
         if ((j4 < Tf) && (i < Nf) && g4 == 0) l_fbits[i] = active ? bits : 0u;
         __syncthreads();
-        const long long next_ray = queue_entry((unsigned int)l_q[qslot ^ 1], my_q);
+        const int next_ray = l_q[qslot ^ 1];
         qslot ^= 1;
 
         // ---- F2 (wave 0, lane = sample): compositing backward -> dL/dz3

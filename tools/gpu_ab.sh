@@ -1,7 +1,8 @@
 #!/bin/bash
 # A/B: bench.py with every variants/libenarf_<name>.so named on the command line (and the in-tree build first)
+# BENCH_ARGS: extra bench flags
 ulimit -c 0
-python bench.py --no-cpu-baseline --steps 300 | python tools/exline.py base
+python bench.py --no-cpu-baseline --steps 300 $BENCH_ARGS | python tools/exline.py base
 for n in "$@"; do
-  ENARF_LIB=$GRAFT_REPO_ROOT/variants/libenarf_$n.so timeout -k 10 120 python bench.py --no-cpu-baseline --steps 300 | python tools/exline.py $n || exit 1
+  ENARF_LIB=$GRAFT_REPO_ROOT/variants/libenarf_$n.so timeout -k 10 120 python bench.py --no-cpu-baseline --steps 300 $BENCH_ARGS | python tools/exline.py $n || exit 1
 done
