@@ -63,8 +63,40 @@ __device__ __forceinline__ float density_head(float sigma_act, uint32_t bits, fl
 }
 
 struct RayRec { float dmin, dmax; uint32_t cand, valid; };
-__host__ __device__ inline size_t ws_records_off() { return 64; }
-__host__ __device__ inline size_t ws_list_off(long long total_rays) { return 64 + (size_t)total_rays * sizeof(RayRec); }
+// workspace: [header kWsHeaderBytes][RayRec x B*n][ray lists: kQueues bands x kClasses cost classes x band_size entries]
+// header (u32): [1] live rays, [16 + q * kClasses + c] entries in list (q, c), [64 + 16 * (q * kClasses + c)] queue head
+// of list (q, c) - one 64-B slot per head, so that the atomics of different lists do not share a cache line
+constexpr int kQueues = 8;
+constexpr int kClasses = 4;
+constexpr int kWsHeadStride = 16;                                    // u32 per queue head slot
+constexpr int kWsHeaderBytes = 256 + kQueues * kClasses * kWsHeadStride * 4;
+__host__ __device__ inline size_t ws_records_off() { return kWsHeaderBytes; }
+__host__ __device__ inline size_t ws_list_off(long long total_rays) { return kWsHeaderBytes + (size_t)total_rays * sizeof(RayRec); }
+// Bands are cut in the padded ray index b * npad + ray (npad = 64 * set-up blocks per image), in multiples of 64, so
+// that the 64 rays of one set-up block always fall into one band.
+__host__ __device__ inline long long ws_npad(int n) { return 64ll * ((n + 63) / 64); }
+__host__ __device__ inline long long ws_band_size(int B, int n) {
+    const long long tot = (long long)B * ws_npad(n);
+    return 64ll * ((tot + 64ll * kQueues - 1) / (64ll * kQueues));
+}
+__host__ __device__ inline size_t ws_total_bytes(int B, int n) {
+    return ws_list_off((long long)B * n) + (size_t)kQueues * kClasses * (size_t)ws_band_size(B, n) * sizeof(uint32_t);
+}
+// cost class of a live ray from the number of candidate parts on its marched segment (which tracks the ray's gather
+// rounds closely: correlation 0.98 on the bench frame): 0 = heaviest
+__device__ __forceinline__ int ray_cost_class(uint32_t cand) {
+#ifndef ENARF_COST_CLASSES
+#define ENARF_COST_CLASSES 1
+#endif
+    const int pc = __popc(cand);
+#if ENARF_COST_CLASSES == 1
+    return pc >= 10 ? 0 : pc >= 6 ? 1 : pc >= 3 ? 2 : 3;
+#elif ENARF_COST_CLASSES == 2      // experiment: lightest first
+    return pc >= 10 ? 3 : pc >= 6 ? 2 : pc >= 3 ? 1 : 0;
+#else
+    return 0;
+#endif
+}
 
 // wave-private compaction of a part bit set into an LDS list; returns the count
 __device__ __forceinline__ int build_cand_list(int *list, uint32_t set, int lane) {
@@ -72,51 +104,68 @@ __device__ __forceinline__ int build_cand_list(int *list, uint32_t set, int lane
     return __popc(set);
 }
 
-// ---- XCD-affine ray queues ---------------------------------------------------------------------------------------
-// The live-ray list (image order) is cut into 8 contiguous bands of equal length, one queue per XCD; a workgroup pulls
-// from the band of the XCD it runs on (HW_REG_XCC_ID) and, when that is drained, steals from the next bands in turn.
-// Each XCD then marches its own part of the image(s): its L2 holds that part's tri-plane texels only, instead of every
-// XCD pulling the whole frame's footprint through its own L2 (8x the fabric reads, and the latency that goes with them).
-// Placement only affects speed: any workgroup may serve any band. ENARF_QUEUE_BANDS=0: blocks of kQBlock entries dealt
-// round-robin to the queues (every XCD sweeps the whole frame), no stealing needed.
-#ifndef ENARF_QUEUE_BANDS
-#define ENARF_QUEUE_BANDS 1
-#endif
-constexpr int kQBlock = 32;
-constexpr int kQueues = 8;
+// ---- XCD-affine, heaviest-first ray queues --------------------------------------------------------------------------
+// The rays are cut into 8 contiguous bands (ws_band_size), one per XCD; within a band the set-up pass files every live
+// ray under its cost class: kQueues x kClasses lists, each with its own queue head. A workgroup works through the
+// classes heaviest first; within a class it pulls from the band of the XCD it runs on (HW_REG_XCC_ID) and, when that
+// list is drained, from the other bands' lists of the same class in turn.
+//  * heaviest first, chip-wide: ray cost spans 10x (1 .. 14 gather rounds per tile) and the heavy rays sit in a few
+//    bands (the torso). Every workgroup helps with them before anyone starts on the cheap rays, so when the queues
+//    drain the rays still in flight are cheap ones and the launch's tail is one cheap ray long;
+//  * bands: within a class each XCD marches its own part of the image(s) first, so its L2 mostly holds that part's
+//    tri-plane texels instead of every XCD pulling the whole frame's footprint through its own L2.
+// Placement and order only affect speed: any workgroup may march any ray.
 __device__ __forceinline__ int xcc_id() {
     return (int)(__builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11)) & 0xF);   // HW_REG_XCC_ID[3:0]
 }
-struct RayQueue {                 // used by one thread of the workgroup
+constexpr int kQueueLdsInts = 4 + kQueues * kClasses;   // 2 x (list, index) slots + the staged list lengths
+struct RayQueue {                 // pop(): one thread of the workgroup; the rest: every thread
     unsigned int *heads;          // kQueues counters in the workspace header
-    long long total, band;
-    int q, tries;
-    __device__ __forceinline__ void init(unsigned int *wsh) {
-        heads = wsh + 2;
-        total = (long long)wsh[1];
-        band = (total + kQueues - 1) / kQueues;
-        q = xcc_id() & (kQueues - 1);
+    const uint32_t *lists;
+    int *l_q;                     // LDS: [slot][2] = (list id or -1, index in the list), then the kQueues x kClasses lengths
+    long long band;
+    int home, q, tries, cls;
+    // every thread; ends with a barrier. The list lengths are final (written by the set-up pass of an earlier launch):
+    // staged once, so that pop() is one atomic and no dependent global loads (a load from a line that is being hit by
+    // atomics from the whole chip takes tens of microseconds).
+    __device__ __forceinline__ void init(void *workspace, int B, int n, int *lds_ints, int tid) {
+        unsigned int *wsh = reinterpret_cast<unsigned int *>(workspace);
+        heads = wsh + 64;
+        lists = reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(workspace) + ws_list_off((long long)B * n));
+        l_q = lds_ints;
+        band = ws_band_size(B, n);
+        home = q = xcc_id() & (kQueues - 1);
         tries = 0;
+        cls = 0;
+        if (tid < kQueues * kClasses) l_q[4 + tid] = (int)wsh[16 + tid];
+        __syncthreads();
     }
-    // next index into the live list, or -1 once every queue is drained
-    __device__ __forceinline__ int pop() {
-#if ENARF_QUEUE_BANDS
-        while (tries < kQueues) {
-            const long long lo = (long long)q * band;
-            const long long len = (total - lo < band) ? total - lo : band;
-            if (len > 0) {
-                const unsigned int j = atomicAdd(heads + q, 1u);
-                if ((long long)j < len) return (int)(lo + j);
+    // one thread: next (list, index) into slot, list = -1 once every list is drained
+    __device__ __forceinline__ void pop(int slot) {
+        int lid = -1, idx = 0;
+        while (cls < kClasses) {
+            while (tries < kQueues) {
+                const int l = q * kClasses + cls;
+                const unsigned int len = (unsigned int)l_q[4 + l];
+                if (len != 0) {
+                    const unsigned int j = atomicAdd(heads + l * kWsHeadStride, 1u);
+                    if (j < len) { lid = l; idx = (int)j; break; }
+                }
+                q = (q + 1) & (kQueues - 1);
+                tries += 1;
             }
-            q = (q + 1) & (kQueues - 1);
-            tries += 1;
+            if (lid >= 0) break;
+            cls += 1;
+            q = home;
+            tries = 0;
         }
-        return -1;
-#else
-        const unsigned int j = atomicAdd(heads + q, 1u);
-        const long long e = ((long long)(j / kQBlock) * kQueues + q) * kQBlock + (j % kQBlock);
-        return e < total ? (int)e : -1;
-#endif
+        l_q[2 * slot] = lid;
+        l_q[2 * slot + 1] = idx;
+    }
+    // every thread, after a barrier that follows pop(slot): the ray id (b * n + ray), or -1
+    __device__ __forceinline__ long long get(int slot) const {
+        const int lid = l_q[2 * slot];
+        return lid < 0 ? -1ll : (long long)lists[(size_t)lid * (size_t)band + (size_t)l_q[2 * slot + 1]];
     }
 };
 

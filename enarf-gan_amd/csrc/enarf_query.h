@@ -20,10 +20,18 @@ namespace enarf {
 #ifndef ENARF_TIMERS
 #define ENARF_TIMERS 0
 #endif
-#if ENARF_TIMERS
+#if ENARF_TIMERS == 2   // round-internal phases: 0 set-up + issue, 1 mask wait, 2 sigmoid, 3 plane-0 wait, 4 reduce 0/1 + issue 2, 5 plane-2 wait, 6 reduce 2, 7 everything else
+#define TMR(S, k) do { } while (0)
+#define TMR2(S, k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); (S).tmr[k] += now_ - (S).tmr_t; (S).tmr_t = now_; } while (0)
+#define TMR2_WAIT(S, k, imm) do { __builtin_amdgcn_s_waitcnt(imm); TMR2(S, k); } while (0)
+#elif ENARF_TIMERS == 1
+#define TMR2(S, k) do { } while (0)
+#define TMR2_WAIT(S, k, imm) do { } while (0)
 #define TMR(S, k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); (S).tmr[k] += now_ - (S).tmr_t; (S).tmr_t = now_; } while (0)
 #else
 #define TMR(S, k) do { } while (0)
+#define TMR2(S, k) do { } while (0)
+#define TMR2_WAIT(S, k, imm) do { } while (0)
 #endif
 
 struct QueryCtx {
@@ -492,6 +500,7 @@ __device__ __forceinline__ void query_tile(const QueryCtx &S, const int *cand_li
         // part probability is formed while they are in flight; plane 2's loads go out as soon as plane 0 is reduced.
         // Two exposed memory latencies per round (the serial form below has five: the compiler splits the mask taps
         // in two waits and each plane waits on its own).
+        TMR2(S, 7);
         if (act) {   // quad-uniform, so the quad broadcasts below see all four lanes
             const int gm = (g == 3) ? 0 : g;   // lane 3 repeats plane 0 (same addresses as lane 0: no extra traffic)
             const char *maskb = reinterpret_cast<const char *>(S.mask);
@@ -505,6 +514,8 @@ __device__ __forceinline__ void query_tile(const QueryCtx &S, const int *cand_li
             tap4u_issue(featb, goff, t0, r0);
             tap4u_issue(featb, goff + fplane_b, t1, r1);
             __builtin_amdgcn_sched_barrier(0);
+            TMR2(S, 0);
+            TMR2_WAIT(S, 1, 0x4F70);     // vmcnt(16)
             float macc = m00 * t.w00;   // part probability plane g (sampling.py:43-48, :62)
             macc += m01 * t.w01;
             macc += m10 * t.w10;
@@ -512,6 +523,8 @@ __device__ __forceinline__ void query_tile(const QueryCtx &S, const int *cand_li
             const float sg = sigmoidf_(macc);
             const float w = (quad_bcast_f<0>(sg) * quad_bcast_f<1>(sg)) * quad_bcast_f<2>(sg);
             float acc[8], s1[8], s2[8];
+            TMR2(S, 2);
+            TMR2_WAIT(S, 3, 0x0F78);     // vmcnt(8)
             tap4u_reduce(r0, t0, acc);
             pin8(acc);      // keep the reduction here: IR-level sinking would otherwise hold all 24 loads' registers
             __builtin_amdgcn_sched_barrier(0);
@@ -521,7 +534,12 @@ __device__ __forceinline__ void query_tile(const QueryCtx &S, const int *cand_li
             tap4u_reduce(r1, t1, s1);
 #pragma unroll
             for (int c = 0; c < 8; ++c) acc[c] += s1[c];
+#if ENARF_TIMERS == 2
+            pin8(acc);
+#endif
             __builtin_amdgcn_sched_barrier(0);
+            TMR2(S, 4);
+            TMR2_WAIT(S, 5, 0x0F70);     // vmcnt(0)
             tap4u_reduce(r2, t2, s2);
 #pragma unroll
             for (int c = 0; c < 8; ++c) acc[c] += s2[c];
@@ -529,6 +547,10 @@ __device__ __forceinline__ void query_tile(const QueryCtx &S, const int *cand_li
             for (int c = 0; c < 8; ++c) feat[c] += acc[c] * w;
             wmax = fmaxf(wmax, w);
             if (DBG && dbg.weight && g == 0) dbg.weight[(size_t)k * dbg.N + dbg.i] = w;
+#if ENARF_TIMERS == 2
+            pin8(feat);
+#endif
+            TMR2(S, 6);
         }
         TMR(S, 3);
 #else

@@ -291,7 +291,7 @@ __device__ __forceinline__ bool ray_hits_part(const float *F, float dx, float dy
 // for the conservative slab tests and the 32 range-test depths (8 each) for the exact cube tests. Rays the
 // reference drops (batch 1, no cube hit: rendering.py:107-110, :337-350) get their zero outputs here and never
 // enter the march; all others are appended to the live list in blocks that keep image order.
-constexpr int kSetupSmemFloats = ENARF_MAX_PARTS * kLdsPartStride + 32 + 12 + 8;
+constexpr int kSetupSmemFloats = ENARF_MAX_PARTS * kLdsPartStride + 32 + 12 + 5 * kClasses;
 
 // RAW: the part frames are computed here from the raw joint poses (same arithmetic as prepare_block, so the values
 // are bit-identical to a.parts) - lets set-up blocks run in the same launch as the prepare blocks. (`raw` stays a
@@ -425,20 +425,33 @@ __device__ __forceinline__ void ray_setup_block(const enarf_render_args &a, cons
         if (a.fine_weights) for (int i = g; i < Nf - 1; i += 4) a.fine_weights[rid * (Nf - 1) + i] = 0.0f;
         if (a.fine_depth) for (int i = g; i < Nf; i += 4) a.fine_depth[rid * Nf + i] = 0.0f;
     }
-    // append the block's live rays, in ray order, to the list
-    const uint64_t bal = __ballot(live && g == 0);
-    if (lane == 0) l_cnt[wave] = __popcll(bal);
+    // file the block's live rays, in ray order, under (band, cost class) - see RayQueue
+    const int cls = ray_cost_class(cand);
+    const bool file_it = live && g == 0;
+    uint64_t bal[kClasses];
+#pragma unroll
+    for (int c = 0; c < kClasses; ++c) {
+        bal[c] = __ballot(file_it && cls == c);
+        if (lane == 0) l_cnt[wave * kClasses + c] = __popcll(bal[c]);
+    }
+    const long long band = ws_band_size(a.B, n);
+    const int q = (int)(((long long)b * ws_npad(n) + 64ll * blk) / band);
+    unsigned int *wsh = reinterpret_cast<unsigned int *>(a.workspace);
     __syncthreads();
-    if (tid == 0) {
-        const int tot = l_cnt[0] + l_cnt[1] + l_cnt[2] + l_cnt[3];
-        l_cnt[4] = tot ? (int)atomicAdd(reinterpret_cast<unsigned int *>(a.workspace) + 1, (unsigned int)tot) : 0;
+    if (tid < kClasses) {
+        const int tot = l_cnt[tid] + l_cnt[kClasses + tid] + l_cnt[2 * kClasses + tid] + l_cnt[3 * kClasses + tid];
+        l_cnt[4 * kClasses + tid] = tot ? (int)atomicAdd(wsh + 16 + q * kClasses + tid, (unsigned int)tot) : 0;
+        if (tot) atomicAdd(wsh + 1, (unsigned int)tot);
     }
     __syncthreads();
-    if (live && g == 0) {
-        int pos = l_cnt[4] + __popcll(bal & ((1ull << lane) - 1ull));
-        for (int wv = 0; wv < wave; ++wv) pos += l_cnt[wv];
-        uint32_t *list = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(a.workspace) + ws_list_off((long long)a.B * n));
-        list[pos] = (uint32_t)rid;
+    if (file_it) {
+        int pos = l_cnt[4 * kClasses + cls];
+        for (int wv = 0; wv < wave; ++wv) pos += l_cnt[wv * kClasses + cls];
+#pragma unroll
+        for (int c = 0; c < kClasses; ++c)
+            if (cls == c) pos += __popcll(bal[c] & ((1ull << lane) - 1ull));
+        uint32_t *lists = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(a.workspace) + ws_list_off((long long)a.B * n));
+        lists[((size_t)q * kClasses + cls) * (size_t)band + pos] = (uint32_t)rid;
     }
 }
 
@@ -493,7 +506,7 @@ constexpr int SC_FH = 648;        // fine: head [4][128]
 constexpr int SC_FBITS = 1160;    // fine: bits [128]
 constexpr int SC_FWMAX = 1288;    // fine: wmax [128]
 constexpr int SC_QUEUE = 1416;    // 2 ray ids (current / prefetched)
-static_assert(SC_QUEUE + 2 <= kScratchFloats, "scratch overflow");
+static_assert(SC_QUEUE + kQueueLdsInts <= kScratchFloats, "scratch overflow");
 
 // SPL = samples per lane in the lane = sample stages: 1 for Nc, Nf <= 64, 2 up to 128 (each wave then loops over two
 // 16-sample tiles per pass)
@@ -505,21 +518,21 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
     // order) from one atomic queue head: perfect load balance whatever the mix of heavy and light rays, and at any
     // moment the whole chip works on a window of a few image rows, whose tri-plane footprint stays in every XCD's L2.
     const int P = a.P, Nc = a.Nc, Nf = a.Nf, n = a.n;
-    unsigned int *wsh = reinterpret_cast<unsigned int *>(a.workspace);
     RayQueue rq;                                            // thread 0's view of the XCD-affine queues
-    rq.init(wsh);
     const RayRec *recs = reinterpret_cast<const RayRec *>(reinterpret_cast<const char *>(a.workspace) + ws_records_off());
-    const uint32_t *live_list = reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(a.workspace) +
-                                                                  ws_list_off((long long)a.B * n));
 
+#if ENARF_TIMERS == 3   // workgroup start / end on the 100 MHz wall clock: how much of the launch is tail
+    const unsigned long long wg_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
     QueryCtx S;
     float *scratch = lds + (lds_total_floats<MODE>(P) - kScratchFloats);
     int *l_q = reinterpret_cast<int *>(scratch + SC_QUEUE);
-    if (tid == 0) l_q[0] = rq.pop();
+    rq.init(a.workspace, a.B, n, l_q, tid);
+    if (tid == 0) rq.pop(0);
     __syncthreads();
-    int cur = l_q[0];
+    int cur = (int)rq.get(0);
     if (cur < 0) return;                      // uniform: every queue is already drained
-    int b = (int)(live_list[cur] / (uint32_t)n);
+    int b = (int)((uint32_t)cur / (uint32_t)n);
     stage_common<MODE>(lds, S, scratch, reinterpret_cast<const char *>(a.mlp_pack) + (size_t)b * kPackBytes,
                        a.parts + (size_t)b * P * kPartStride, a.canonical_pose, P, tid, 256);
     S.feat = a.feat_cl + (size_t)b * a.feat_batch_stride;
@@ -546,8 +559,8 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
     S.tmr_t = __builtin_amdgcn_s_memtime();
 #endif
     while (cur >= 0) {
-        if (tid == 0) l_q[qslot ^ 1] = rq.pop();   // prefetch the next entry; read after the S1 barrier
-        const uint32_t rid = live_list[cur];
+        if (tid == 0) rq.pop(qslot ^ 1);   // prefetch the next entry; read after the S1 barrier
+        const uint32_t rid = (uint32_t)cur;
         const int nb = (int)(rid / (uint32_t)n), ray = (int)(rid - (uint32_t)nb * (uint32_t)n);
         if (nb != b) {   // next image: restage its MLP pack and part frames (the list is in image order, so this is rare)
             b = nb;
@@ -597,7 +610,7 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
         TMR(S, 4);
         __syncthreads();
         TMR(S, 5);
-        const int next_ray = l_q[qslot ^ 1];
+        const int next_ray = (int)rq.get(qslot ^ 1);
         qslot ^= 1;
 
         // ---- S2 (every wave, element e = 64 s + lane): weights (rendering.py:180-184), smoothing (:187-190), bins (:192-197)
@@ -773,11 +786,23 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
             }
         }
         TMR(S, 7);
+        TMR2(S, 7);
         // no barrier needed here: coarse arrays are rewritten in S1' (after this ray's S3 barrier, which follows every
         // wave's S2 reads), fine arrays in S3' (after the S1' barrier, which wave 0 reaches only after this S4).
         cur = next_ray;
     }
-#if ENARF_TIMERS
+#if ENARF_TIMERS == 3
+    if (a.counters && tid == 0) {
+        const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+        atomicMin(&a.counters[0], wg_t0);
+        atomicMax(&a.counters[1], t1);
+        atomicAdd(&a.counters[2], t1 - wg_t0);
+        atomicAdd(&a.counters[3], 1ull);
+        atomicMax(&a.counters[4], wg_t0);
+        atomicMin(&a.counters[5], t1);
+    }
+    return;
+#elif ENARF_TIMERS
     if (a.counters && lane == 0)
         for (int k = 0; k < 8; ++k) atomicAdd(&a.counters[k], S.tmr[k]);
     return;
@@ -879,7 +904,7 @@ extern "C" int enarf_query_fwd(const enarf_query_args *args, enarf_stream_t stre
 namespace enarf {
 // zero the workspace header and run the ray set-up pre-pass (also used by the backward)
 int launch_ray_setup(const enarf_render_args &a, hipStream_t st) {
-    hipError_t e = hipMemsetAsync(a.workspace, 0, 64, st);
+    hipError_t e = hipMemsetAsync(a.workspace, 0, kWsHeaderBytes, st);
     if (e != hipSuccess) return host::fail((int)e, "ray set-up: hipMemsetAsync(workspace) failed: %s", hipGetErrorString(e));
     const int bpi = (a.n + 63) / 64;
     hipLaunchKernelGGL(ray_setup_kernel, dim3((unsigned)(bpi * a.B)), dim3(256), 0, st, a, bpi);
@@ -918,8 +943,7 @@ static int launch_render(const enarf_render_args &a, hipStream_t st, bool with_s
 
 extern "C" size_t enarf_render_workspace_bytes(int B, int n) {
     if (B <= 0 || n <= 0) return 0;
-    const long long total = (long long)B * n;
-    return (ws_list_off(total) + (size_t)total * sizeof(uint32_t) + 63) & ~(size_t)63;
+    return (ws_total_bytes(B, n) + 63) & ~(size_t)63;
 }
 
 static int check_render(const enarf_render_args &a) {
@@ -969,7 +993,7 @@ extern "C" int enarf_render_step_fwd(const enarf_prepare_args *prep, const float
     if (!(phases & ENARF_STEP_ALL) || (phases & ~ENARF_STEP_ALL)) return host::fail(ENARF_ERR_ARG, "enarf_render_step_fwd: bad phases %d", phases);
     hipStream_t st = (hipStream_t)stream;
     if (!(phases & ENARF_STEP_PRE)) return dispatch_march(r, st, false);
-    hipError_t e = hipMemsetAsync(r.workspace, 0, 64, st);
+    hipError_t e = hipMemsetAsync(r.workspace, 0, kWsHeaderBytes, st);
     if (e != hipSuccess) return host::fail((int)e, "enarf_render_step_fwd: hipMemsetAsync(workspace) failed: %s", hipGetErrorString(e));
     PreParams q;
     q.prep = p; q.rend = r; q.tri = tri_nchw; q.feat_cl = feat_cl; q.tri_B = tri_B; q.ch_total = channels_total;

@@ -25,7 +25,7 @@ constexpr int SB_FH = 128;        // head [4][64]
 constexpr int SB_FBITS = 384;     // bits [64]
 constexpr int SB_DZ3 = 448;       // dL/dz3 [4][64]
 constexpr int SB_QUEUE = 704;     // 2 ray ids
-static_assert(SB_QUEUE + 2 <= kScratchFloats, "scratch overflow");
+static_assert(SB_QUEUE + kQueueLdsInts <= kScratchFloats, "scratch overflow");
 
 constexpr int kTRow = 33;                       // floats per texel row of the transpose tile (32 + 1 pad)
 constexpr int kTTile = 16 * kTRow + 16;          // 16 texel rows + 16 texel offsets (ints)
@@ -75,19 +75,16 @@ __global__ __launch_bounds__(256, kBwdWavesPerSimd) void render_bwd_kernel(const
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int P = a.P, Nf = a.Nf, n = a.n;
-    unsigned int *wsh = reinterpret_cast<unsigned int *>(a.workspace);
     RayQueue rq;
-    rq.init(wsh);
     const RayRec *recs = reinterpret_cast<const RayRec *>(reinterpret_cast<const char *>(a.workspace) + ws_records_off());
-    const uint32_t *live_list = reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(a.workspace) +
-                                                                  ws_list_off((long long)a.B * n));
     // LDS: [fp32 weights PK_B1][bias 144][transposed PKT_FLOATS][parts][canon][scratch]
     float *l_w = lds, *l_bias = l_w + PK_B1, *l_wt = l_bias + 144, *l_parts = l_wt + PKT_FLOATS;
     float *l_canon = l_parts + P * kLdsPartStride, *scratch = l_canon + P * kLdsCanonStride;
     int *l_q = reinterpret_cast<int *>(scratch + SB_QUEUE);
-    if (tid == 0) l_q[0] = rq.pop();
+    rq.init(a.workspace, a.B, n, l_q, tid);
+    if (tid == 0) rq.pop(0);
     __syncthreads();
-    int cur = l_q[0];
+    int cur = (int)rq.get(0);
     if (cur < 0) return;
     int b = -1;
     QueryCtx S;
@@ -104,8 +101,8 @@ __global__ __launch_bounds__(256, kBwdWavesPerSimd) void render_bwd_kernel(const
     float *gfeat = nullptr, *gmask = nullptr;
 
     while (cur >= 0) {
-        if (tid == 0) l_q[qslot ^ 1] = rq.pop();
-        const uint32_t rid = live_list[cur];
+        if (tid == 0) rq.pop(qslot ^ 1);
+        const uint32_t rid = (uint32_t)cur;
         const int nb = (int)(rid / (uint32_t)n), ray = (int)(rid - (uint32_t)nb * (uint32_t)n);
         if (nb != b) {   // (re)stage the image's weights (forward + transposed), biases and frames
             if (b >= 0) __syncthreads();
@@ -217,7 +214,7 @@ __global__ __launch_bounds__(256, kBwdWavesPerSimd) void render_bwd_kernel(const
         }
         if ((j4 < Tf) && (i < Nf) && g4 == 0) l_fbits[i] = active ? bits : 0u;
         __syncthreads();
-        const int next_ray = l_q[qslot ^ 1];
+        const int next_ray = (int)rq.get(qslot ^ 1);
         qslot ^= 1;
 
         // ---- F2 (wave 0, lane = sample): compositing backward -> dL/dz3

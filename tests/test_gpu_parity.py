@@ -376,3 +376,21 @@ def test_fused_step_rejects_mismatched_buffers(ops):
     st.ra.parts = st.parts.data_ptr()
     with pytest.raises(RuntimeError, match="phases"):
         st.run(0)
+
+
+def test_render_ragged_ray_count_batch3_every_ray_marched_once(ops):
+    """n not a multiple of the 64-ray set-up blocks, B = 3: the banded, cost-classed ray lists must hand out every
+    live ray exactly once (outputs for all rays, equal to the oracle; the live-ray counter equals B * n since batches
+    > 1 drop nothing)."""
+    sc = Scene(32, 3, "center+head", 20)
+    ds = DeviceScene(sc)
+    g = torch.Generator().manual_seed(3)
+    idx = torch.randperm(32 * 32, generator=g)[:333].sort().values
+    coord = sc.raw["image_coord"][..., idx].contiguous()
+    bins = torch.rand(3, 333, 32, generator=g).sort(-1).values
+    out = ds.render(coord, 24, 32, bins, count=True)
+    rc, rm, rd = sc.oracle_render(coord, 24, 32, bins, taps=False)
+    assert_close(_cpu(out.color), rc, "colour")
+    assert_close(_cpu(out.mask), rm, "mask")
+    assert_close(_cpu(out.disparity), rd, "disparity")
+    assert int(_cpu(out.counters)[2]) == 3 * 333

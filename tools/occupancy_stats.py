@@ -43,3 +43,13 @@ nv = (cnt > 0).sum(1)
 print("valid samples per ray: mean", nv.mean(), "hist", np.bincount(nv, minlength=49)[::4])
 # pair-level bound
 print("pair-level bound rounds (pairs/64 per WG round):", np.ceil(cnt.sum(1) / 64).mean())
+# ---- per-ray cost distribution (tail analysis): coarse pairs per ray and parts touched
+pairs = cnt.sum(1)
+parts_touched = val.any(2).sum(0).numpy()      # (m,) parts with >= 1 valid coarse sample
+print("pairs/ray percentiles 10/50/90/99/max", np.percentile(pairs, [10, 50, 90, 99, 100]))
+print("critical rounds/ray percentiles", np.percentile(seg.max(1), [10, 50, 90, 99, 100]))
+print("parts touched percentiles", np.percentile(parts_touched, [10, 50, 90, 99, 100]))
+print("corr(pairs, parts touched)", np.corrcoef(pairs, parts_touched)[0, 1], "corr(crit rounds, parts)", np.corrcoef(seg.max(1), parts_touched)[0, 1])
+for T in (4, 6, 8, 10):
+    hv = parts_touched >= T
+    print(f"T={T}: heavy frac {hv.mean():.2f}  mean crit rounds heavy {seg.max(1)[hv].mean():.2f} light {seg.max(1)[~hv].mean() if (~hv).any() else 0:.2f}")
