@@ -71,19 +71,26 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
     return v;
 }
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+// DPP data movement (no LDS crossbar round trip as with ds_bpermute): v from the lane `ctrl` names, 0 where the row is
+// masked off or the source lane is out of range
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
+// inclusive prefix sum across the 64 lanes: Hillis-Steele inside each row of 16 (row_shr 1, 2, 4, 8), then the row
+// totals hop across (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3) - six dependent VALU ops
+__device__ __forceinline__ float wave_scan_incl(float v, int lane) {
+    (void)lane;
+    v += dpp_f<0x111, 0xF>(v);
+    v += dpp_f<0x112, 0xF>(v);
+    v += dpp_f<0x114, 0xF>(v);
+    v += dpp_f<0x118, 0xF>(v);
+    v += dpp_f<0x142, 0xA>(v);
+    v += dpp_f<0x143, 0xC>(v);
     return v;
 }
-// inclusive prefix sum across the 64 lanes
-__device__ __forceinline__ float wave_scan_incl(float v, int lane) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        float t = __shfl_up(v, o);
-        if (lane >= o) v += t;
-    }
-    return v;
+__device__ __forceinline__ float wave_sum(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wave_scan_incl(v, 0)), 63));
 }
 
 // ---- "wave vectors": SPL values per lane = SPL * 64 elements along a ray, element e = 64 s + lane --------------------
@@ -110,16 +117,16 @@ __device__ __forceinline__ void wv_prev(const float v[SPL], float out[SPL], int 
     float carry = 0.0f;
 #pragma unroll
     for (int s = 0; s < SPL; ++s) {
-        const float up = __shfl_up(v[s], 1);
+        const float up = dpp_f<0x138, 0xF>(v[s]);      // wave_shr:1
         out[s] = (lane == 0) ? carry : up;
-        carry = __shfl(v[s], 63);
+        if (s + 1 < SPL) carry = __shfl(v[s], 63);
     }
 }
 template <int SPL>
 __device__ __forceinline__ void wv_next(const float v[SPL], float out[SPL], int lane) {    // out[e] = v[e+1] (last: 0)
 #pragma unroll
     for (int s = 0; s < SPL; ++s) {
-        const float dn = __shfl_down(v[s], 1);
+        const float dn = dpp_f<0x130, 0xF>(v[s]);      // wave_shl:1
         const float nxt = (s + 1 < SPL) ? __shfl(v[(s + 1 < SPL) ? s + 1 : s], 0) : 0.0f;
         out[s] = (lane == 63) ? nxt : dn;
     }

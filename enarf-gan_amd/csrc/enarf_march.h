@@ -64,12 +64,17 @@ __device__ __forceinline__ float density_head(float sigma_act, uint32_t bits, fl
 
 struct RayRec { float dmin, dmax; uint32_t cand, valid; };
 // workspace: [header kWsHeaderBytes][RayRec x B*n][ray lists: kQueues bands x kClasses cost classes x band_size entries]
-// header (u32): [1] live rays, [16 + q * kClasses + c] entries in list (q, c), [64 + 16 * (q * kClasses + c)] queue head
+// header (u32): [1] live rays, [kWsCountsOff + q * kClasses + c] entries in list (q, c), [kWsHeadsOff + 16 * (q * kClasses + c)] queue head
 // of list (q, c) - one 64-B slot per head, so that the atomics of different lists do not share a cache line
 constexpr int kQueues = 8;
-constexpr int kClasses = 4;
+#ifndef ENARF_NUM_CLASSES
+#define ENARF_NUM_CLASSES 4
+#endif
+constexpr int kClasses = ENARF_NUM_CLASSES;
+constexpr int kWsCountsOff = 16;                                     // u32 index of the list lengths
+constexpr int kWsHeadsOff = (kWsCountsOff + kQueues * kClasses + 15) / 16 * 16;   // u32 index of the first queue head
 constexpr int kWsHeadStride = 16;                                    // u32 per queue head slot
-constexpr int kWsHeaderBytes = 256 + kQueues * kClasses * kWsHeadStride * 4;
+constexpr int kWsHeaderBytes = (kWsHeadsOff + kQueues * kClasses * kWsHeadStride) * 4;
 __host__ __device__ inline size_t ws_records_off() { return kWsHeaderBytes; }
 __host__ __device__ inline size_t ws_list_off(long long total_rays) { return kWsHeaderBytes + (size_t)total_rays * sizeof(RayRec); }
 // Bands are cut in the padded ray index b * npad + ray (npad = 64 * set-up blocks per image), in multiples of 64, so
@@ -89,7 +94,11 @@ __device__ __forceinline__ int ray_cost_class(uint32_t cand) {
 #define ENARF_COST_CLASSES 1
 #endif
     const int pc = __popc(cand);
-#if ENARF_COST_CLASSES == 1
+#if ENARF_COST_CLASSES == 1 && ENARF_NUM_CLASSES == 8
+    return pc >= 12 ? 0 : pc >= 10 ? 1 : pc >= 8 ? 2 : pc >= 6 ? 3 : pc >= 4 ? 4 : pc == 3 ? 5 : pc == 2 ? 6 : 7;
+#elif ENARF_COST_CLASSES == 1 && ENARF_NUM_CLASSES == 2
+    return pc >= 6 ? 0 : 1;
+#elif ENARF_COST_CLASSES == 1
     return pc >= 10 ? 0 : pc >= 6 ? 1 : pc >= 3 ? 2 : 3;
 #elif ENARF_COST_CLASSES == 2      // experiment: lightest first
     return pc >= 10 ? 3 : pc >= 6 ? 2 : pc >= 3 ? 1 : 0;
@@ -130,14 +139,18 @@ struct RayQueue {                 // pop(): one thread of the workgroup; the res
     // atomics from the whole chip takes tens of microseconds).
     __device__ __forceinline__ void init(void *workspace, int B, int n, int *lds_ints, int tid) {
         unsigned int *wsh = reinterpret_cast<unsigned int *>(workspace);
-        heads = wsh + 64;
+        heads = wsh + kWsHeadsOff;
         lists = reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(workspace) + ws_list_off((long long)B * n));
         l_q = lds_ints;
         band = ws_band_size(B, n);
+#ifdef ENARF_NO_HOME_BAND
+        home = q = (int)(blockIdx.x & (kQueues - 1));
+#else
         home = q = xcc_id() & (kQueues - 1);
+#endif
         tries = 0;
         cls = 0;
-        if (tid < kQueues * kClasses) l_q[4 + tid] = (int)wsh[16 + tid];
+        if (tid < kQueues * kClasses) l_q[4 + tid] = (int)wsh[kWsCountsOff + tid];
         __syncthreads();
     }
     // one thread: next (list, index) into slot, list = -1 once every list is drained

@@ -24,6 +24,11 @@ namespace enarf {
 #define TMR(S, k) do { } while (0)
 #define TMR2(S, k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); (S).tmr[k] += now_ - (S).tmr_t; (S).tmr_t = now_; } while (0)
 #define TMR2_WAIT(S, k, imm) do { __builtin_amdgcn_s_waitcnt(imm); TMR2(S, k); } while (0)
+#elif ENARF_TIMERS == 4  // ray-level stages: 0 header, 1 S2 weights, 2 S2 sampling, 3 S4 heads, 4 S4 scan, 5 S4 sums + stores, 6 barriers, 7 rest
+#define TMR(S, k) do { } while (0)
+#define TMR2(S, k) do { } while (0)
+#define TMR2_WAIT(S, k, imm) do { } while (0)
+#define TMR4(S, k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); (S).tmr[k] += now_ - (S).tmr_t; (S).tmr_t = now_; } while (0)
 #elif ENARF_TIMERS == 1
 #define TMR2(S, k) do { } while (0)
 #define TMR2_WAIT(S, k, imm) do { } while (0)
@@ -32,6 +37,10 @@ namespace enarf {
 #define TMR(S, k) do { } while (0)
 #define TMR2(S, k) do { } while (0)
 #define TMR2_WAIT(S, k, imm) do { } while (0)
+#endif
+
+#ifndef TMR4
+#define TMR4(S, k) do { } while (0)
 #endif
 
 struct QueryCtx {

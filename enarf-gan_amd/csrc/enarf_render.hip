@@ -440,7 +440,7 @@ __device__ __forceinline__ void ray_setup_block(const enarf_render_args &a, cons
     __syncthreads();
     if (tid < kClasses) {
         const int tot = l_cnt[tid] + l_cnt[kClasses + tid] + l_cnt[2 * kClasses + tid] + l_cnt[3 * kClasses + tid];
-        l_cnt[4 * kClasses + tid] = tot ? (int)atomicAdd(wsh + 16 + q * kClasses + tid, (unsigned int)tot) : 0;
+        l_cnt[4 * kClasses + tid] = tot ? (int)atomicAdd(wsh + kWsCountsOff + q * kClasses + tid, (unsigned int)tot) : 0;
         if (tot) atomicAdd(wsh + 1, (unsigned int)tot);
     }
     __syncthreads();
@@ -558,7 +558,13 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
     for (int k = 0; k < 8; ++k) S.tmr[k] = 0;
     S.tmr_t = __builtin_amdgcn_s_memtime();
 #endif
+#if ENARF_TIMERS == 3
+    unsigned long long ray_t0 = wg_t0, ray_max = 0;
+#endif
     while (cur >= 0) {
+#if ENARF_TIMERS == 3
+        { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); if (now - ray_t0 > ray_max && n_rays) ray_max = now - ray_t0; ray_t0 = now; }
+#endif
         if (tid == 0) rq.pop(qslot ^ 1);   // prefetch the next entry; read after the S1 barrier
         const uint32_t rid = (uint32_t)cur;
         const int nb = (int)(rid / (uint32_t)n), ray = (int)(rid - (uint32_t)nb * (uint32_t)n);
@@ -586,6 +592,7 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
         const float sx = exact_mul(dmin, dx), sy = exact_mul(dmin, dy), sz = exact_mul(dmin, dz);
         const float ex = exact_mul(dmax, dx), ey = exact_mul(dmax, dy), ez = exact_mul(dmax, dz);
         TMR(S, 0);
+        TMR4(S, 0);
 
         // ---- S1: coarse pass, wave w owns bins [w Tc, (w+1) Tc), 16 at a time  (rendering.py:119-131, :172)
 #pragma unroll
@@ -608,8 +615,10 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
             if (active && (lane & 3) == 0) { l_cbits[i] = bits; l_cwmax[i] = wmax; }
         }
         TMR(S, 4);
+        TMR4(S, 7);
         __syncthreads();
         TMR(S, 5);
+        TMR4(S, 6);
         const int next_ray = (int)rq.get(qslot ^ 1);
         qslot ^= 1;
 
@@ -644,6 +653,7 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
                 if (e >= Nc - 1) wr[s] = 0.0f;
                 ws[s] = (e < Nc) ? (fmaxf(wl[s], wgt[s]) + fmaxf(wgt[s], wr[s])) / 2.0f + 0.01f : 0.0f;
             }
+            TMR4(S, 1);
             if (ablate & 8) {
 #pragma unroll
                 for (int s = 0; s < SPL; ++s) bin[s] = (float)(64 * s + lane) / (float)Nf;
@@ -705,6 +715,7 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
         }
 
         TMR(S, 6);
+        TMR4(S, 2);
         // ---- S3: fine pass, wave w owns samples [w Tf, (w+1) Tf); the last sample only closes the last interval
 #pragma unroll
         for (int u = 0; u < SPL; ++u) {
@@ -727,8 +738,10 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
             if (skip_tile[u] && lane == 0) n_skipped += 1;
         }
         TMR(S, 4);
+        TMR4(S, 7);
         __syncthreads();
         TMR(S, 5);
+        TMR4(S, 6);
 
         // ---- S4 (wave 0, element e = 64 s + lane): compositing (rendering.py:307-335)
         if (wave == 0) {
@@ -753,6 +766,7 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
                     }
                 }
             }
+            TMR4(S, 3);
             wv_next<SPL>(fdepth, dnext, lane);
 #pragma unroll
             for (int s = 0; s < SPL; ++s) {
@@ -769,6 +783,7 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
                 vr[s] = wgt[s] * cr[s]; vg[s] = wgt[s] * cg[s]; vb[s] = wgt[s] * cb[s];
                 vd[s] = seg ? (wgt[s] * 1.0f) / fdepth[s] : 0.0f;
             }
+            TMR4(S, 4);
             const float o_r = wv_sum<SPL>(vr), o_g = wv_sum<SPL>(vg), o_b = wv_sum<SPL>(vb);
             const float o_m = wv_sum<SPL>(wgt), o_d = wv_sum<SPL>(vd);
             if (lane == 0) {
@@ -787,6 +802,7 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
         }
         TMR(S, 7);
         TMR2(S, 7);
+        TMR4(S, 5);
         // no barrier needed here: coarse arrays are rewritten in S1' (after this ray's S3 barrier, which follows every
         // wave's S2 reads), fine arrays in S3' (after the S1' barrier, which wave 0 reaches only after this S4).
         cur = next_ray;
@@ -800,6 +816,8 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
         atomicAdd(&a.counters[3], 1ull);
         atomicMax(&a.counters[4], wg_t0);
         atomicMin(&a.counters[5], t1);
+        atomicAdd(&a.counters[6], t1 - ray_t0);      // duration of this workgroup's last ray
+        atomicMax(&a.counters[7], ray_max);          // longest ray of the launch
     }
     return;
 #elif ENARF_TIMERS

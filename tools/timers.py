@@ -18,7 +18,7 @@ names2 = ["0 round set-up + issue p0 p1", "1 mask wait", "2 sigmoid", "3 plane-0
           "6 reduce p2 + finish", "7 everything outside the rounds"]
 names = ["0 ray header", "1 pass A (candidate tests)", "2 round set-up + mask taps", "3 feature gathers + FMA",
          "4 transpose + MLP", "5 barrier wait", "6 S2 weights/sampling", "7 S4 composite"]
-for rep in range(3):
+for rep in range(12):
     st = ops.RenderStep(d["pose_to_camera"], d["bone_length"], cbl.to(dev), d["z_rend"], mlp, sc["parents"], "center_fixed",
                         3.0, d["image_coord"].reshape(1, 3, S * S), d["inv_intrinsics"], cpose.to(dev), tri, feat, Nc, Nf,
                         seed=99, mlp_mode=os.environ.get("MODE", "f16x3"), count=True)
@@ -29,11 +29,15 @@ for rep in range(3):
     torch.cuda.synchronize()
 if os.environ.get("TIMERS") == "2":
     names = names2
+if os.environ.get("TIMERS") == "4":
+    names = ["0 ray header (queue, record, direction)", "1 S2 weights (density, scan, smoothing)", "2 S2 sampling (philox, cdf, search)",
+             "3 S4 heads (tanh, density)", "4 S4 scan + weights", "5 S4 sums + stores", "6 barrier waits", "7 S1 + S3 (queries)"]
 if os.environ.get("TIMERS") == "3":
     c = out.counters.cpu().tolist()
     span = c[1] - c[0]
     print(f"workgroups {c[3]}  launch span {span / 100:.1f} us  mean workgroup busy {c[2] / c[3] / 100:.1f} us "
-          f"({c[2] / c[3] / span * 100:.1f} % of the span)  last start +{(c[4] - c[0]) / 100:.1f} us  first end +{(c[5] - c[0]) / 100:.1f} us")
+          f"({c[2] / c[3] / span * 100:.1f} % of the span)  last start +{(c[4] - c[0]) / 100:.1f} us  first end +{(c[5] - c[0]) / 100:.1f} us  "
+          f"mean last-ray {c[6] / c[3] / 100:.1f} us  longest ray {c[7] / 100:.1f} us")
     sys.exit(0)
 c = out.counters.cpu().double()
 tot = float(c.sum())
