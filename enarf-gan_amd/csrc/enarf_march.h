@@ -62,7 +62,9 @@ __device__ __forceinline__ float density_head(float sigma_act, uint32_t bits, fl
     return bits ? d : 0.0f;
 }
 
-struct RayRec { float dmin, dmax; uint32_t cand, valid; };
+// what the set-up pass leaves for the march: depth range, candidate parts, hit flag and the ray direction K^-1 [u v w]
+struct __attribute__((aligned(16))) RayRec { float dmin, dmax; uint32_t cand, valid; float dx, dy, dz, pad; };
+static_assert(sizeof(RayRec) == 32, "RayRec");
 // workspace: [header kWsHeaderBytes][RayRec x B*n][ray lists: kQueues bands x kClasses cost classes x band_size entries]
 // header (u32): [1] live rays, [kWsCountsOff + q * kClasses + c] entries in list (q, c), [kWsHeadsOff + 16 * (q * kClasses + c)] queue head
 // of list (q, c) - one 64-B slot per head, so that the atomics of different lists do not share a cache line
@@ -153,7 +155,34 @@ struct RayQueue {                 // pop(): one thread of the workgroup; the res
         if (tid < kQueues * kClasses) l_q[4 + tid] = (int)wsh[kWsCountsOff + tid];
         __syncthreads();
     }
-    // one thread: next (list, index) into slot, list = -1 once every list is drained
+    // one thread. pop_begin() issues the atomic on the current list, pop_end() - called as late as possible, so that
+    // the atomic's round trip overlaps with work - files the result under slot and, when that list turned out to be
+    // drained, goes on to the next ones. List = -1 once every list is drained.
+    unsigned int pend_j;
+    int pend_l;
+    __device__ __forceinline__ void pop_begin() {
+        pend_l = -1;
+        pend_j = 0;
+        if (cls < kClasses && tries < kQueues) {
+            const int l = q * kClasses + cls;
+            if (l_q[4 + l] != 0) {
+                pend_l = l;
+                pend_j = atomicAdd(heads + l * kWsHeadStride, 1u);
+            }
+        }
+    }
+    __device__ __forceinline__ void pop_end(int slot) {
+        if (pend_l >= 0 && pend_j < (unsigned int)l_q[4 + pend_l]) {
+            l_q[2 * slot] = pend_l;
+            l_q[2 * slot + 1] = (int)pend_j;
+            return;
+        }
+        if (cls < kClasses) {   // the speculated list is empty or drained: move on
+            q = (q + 1) & (kQueues - 1);
+            tries += 1;
+        }
+        pop(slot);
+    }
     __device__ __forceinline__ void pop(int slot) {
         int lid = -1, idx = 0;
         while (cls < kClasses) {

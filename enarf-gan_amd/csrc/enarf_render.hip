@@ -4,6 +4,12 @@
 #include "enarf_host.h"
 #include <cstdlib>
 
+#ifndef ENARF_SPLIT_POP
+#define ENARF_SPLIT_POP 0
+#endif
+#ifndef ENARF_PREFETCH_REC
+#define ENARF_PREFETCH_REC 0
+#endif
 #ifndef ENARF_RENDER_WAVES_PER_SIMD
 #define ENARF_RENDER_WAVES_PER_SIMD 3
 #endif
@@ -412,7 +418,7 @@ __device__ __forceinline__ void ray_setup_block(const enarf_render_args &a, cons
     const size_t rid = (size_t)b * n + rc;
     if (in_range && g == 0) {
         RayRec *recs = reinterpret_cast<RayRec *>(reinterpret_cast<char *>(a.workspace) + ws_records_off());
-        recs[rid] = RayRec{dmin, dmax, cand, ray_valid ? 1u : 0u};
+        recs[rid] = RayRec{dmin, dmax, cand, ray_valid ? 1u : 0u, dx, dy, dz, 0.0f};
         if (a.dbg_depth_min) {
             a.dbg_depth_min[rid] = dmin;
             a.dbg_depth_max[rid] = dmax;
@@ -561,14 +567,21 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
 #if ENARF_TIMERS == 3
     unsigned long long ray_t0 = wg_t0, ray_max = 0;
 #endif
+#if ENARF_PREFETCH_REC
+    RayRec nrec = recs[cur];
+#endif
     while (cur >= 0) {
 #if ENARF_TIMERS == 3
         { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); if (now - ray_t0 > ray_max && n_rays) ray_max = now - ray_t0; ray_t0 = now; }
 #endif
-        if (tid == 0) rq.pop(qslot ^ 1);   // prefetch the next entry; read after the S1 barrier
+#if ENARF_SPLIT_POP
+        if (tid == 0) rq.pop_begin();      // next entry: the atomic flies during S1; filed before the S1 barrier
+#else
+        if (tid == 0) rq.pop(qslot ^ 1);   // next entry; read after the S1 barrier
+#endif
         const uint32_t rid = (uint32_t)cur;
         const int nb = (int)(rid / (uint32_t)n), ray = (int)(rid - (uint32_t)nb * (uint32_t)n);
-        if (nb != b) {   // next image: restage its MLP pack and part frames (the list is in image order, so this is rare)
+        if (nb != b) {   // next image: restage its MLP pack and part frames (the lists are in image order, so this is rare)
             b = nb;
             __syncthreads();
             stage_common<MODE>(lds, S, scratch, reinterpret_cast<const char *>(a.mlp_pack) + (size_t)b * kPackBytes,
@@ -577,15 +590,14 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
             S.mask = a.mask_planes + (size_t)b * a.mask_batch_stride;
             __syncthreads();
         }
-        const float *coord = a.image_coord + (size_t)b * 3 * n;
-        const float *Ki = a.inv_intrinsics + (size_t)b * 9;
-        // ---- ray direction K^-1 [u v w]  (rendering.py:26-38)
-        const float u = coord[ray], v = coord[n + ray], w = coord[2 * n + ray];
-        const float dx = exact_dot3(Ki[0], u, Ki[1], v, Ki[2], w);
-        const float dy = exact_dot3(Ki[3], u, Ki[4], v, Ki[5], w);
-        const float dz = exact_dot3(Ki[6], u, Ki[7], v, Ki[8], w);
-        // depth range and candidate parts: from the set-up pre-pass
+        // depth range, candidate parts and ray direction K^-1 [u v w] (rendering.py:26-38): from the set-up pre-pass,
+        // fetched while the previous ray was still being marched
+#if ENARF_PREFETCH_REC
+        const RayRec rec = nrec;
+#else
         const RayRec rec = recs[rid];
+#endif
+        const float dx = rec.dx, dy = rec.dy, dz = rec.dz;
         const float dmin = rec.dmin, dmax = rec.dmax;
         if (wave == 0) n_rays += 1;
         const int ncand = build_cand_list(l_cand, rec.cand, lane);
@@ -616,6 +628,9 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
         }
         TMR(S, 4);
         TMR4(S, 7);
+#if ENARF_SPLIT_POP
+        if (tid == 0) rq.pop_end(qslot ^ 1);
+#endif
         __syncthreads();
         TMR(S, 5);
         TMR4(S, 6);
@@ -714,6 +729,9 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
             }
         }
 
+#if ENARF_PREFETCH_REC
+        nrec = recs[max(next_ray, 0)];     // the list entry has arrived by now; the record flies during S3 / S4
+#endif
         TMR(S, 6);
         TMR4(S, 2);
         // ---- S3: fine pass, wave w owns samples [w Tf, (w+1) Tf); the last sample only closes the last interval

@@ -125,13 +125,8 @@ __global__ __launch_bounds__(256, kBwdWavesPerSimd) void render_bwd_kernel(const
             gmask = a.grad_mask_planes + (size_t)b * a.grad_mask_batch_stride;
             __syncthreads();
         }
-        const float *coord = a.image_coord + (size_t)b * 3 * n;
-        const float *Ki = a.inv_intrinsics + (size_t)b * 9;
-        const float u = coord[ray], v = coord[n + ray], w = coord[2 * n + ray];
-        const float dx_ = exact_dot3(Ki[0], u, Ki[1], v, Ki[2], w);
-        const float dy_ = exact_dot3(Ki[3], u, Ki[4], v, Ki[5], w);
-        const float dz_ = exact_dot3(Ki[6], u, Ki[7], v, Ki[8], w);
-        const RayRec rec = recs[rid];
+        const RayRec rec = recs[rid];      // depth range, candidates and ray direction from the set-up pass
+        const float dx_ = rec.dx, dy_ = rec.dy, dz_ = rec.dz;
         const float dmin = rec.dmin, dmax = rec.dmax;
         const int ncand = build_cand_list(l_cand, rec.cand, lane);
         const float sx = exact_mul(dmin, dx_), sy = exact_mul(dmin, dy_), sz = exact_mul(dmin, dz_);
