@@ -556,7 +556,7 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
     unsigned n_pairs = 0, n_tiles = 0, n_rays = 0, n_rounds = 0, n_skipped = 0;
     int qslot = 0;
     const QueryDbg nodbg{nullptr, nullptr, 0, 0};
-    const int Tc = (Nc + 3) >> 2, Tf = (Nf + 3) >> 2;     // samples per wave (<= 16)
+    const int Tf = (Nf + 3) >> 2;                          // fine samples per wave (<= 16 SPL)
     const int j4 = lane >> 2;                              // this lane's sample within the wave's tile
     const bool dbgq = (a.dbg_fine_density != nullptr);
 
@@ -606,25 +606,30 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
         TMR(S, 0);
         TMR4(S, 0);
 
-        // ---- S1: coarse pass, wave w owns bins [w Tc, (w+1) Tc), 16 at a time  (rendering.py:119-131, :172)
+        // ---- S1: coarse pass (rendering.py:119-131, :172) in FULL tiles of 16 bins: tile t of the ray goes to wave slot
+        // t / SPL. With Nc = 48 that is three full tiles instead of four tiles of 12 - a quarter fewer gather rounds
+        // and MLP tiles for the same critical path - and the spared wave rotates ray by ray so that no SIMD idles.
+        {
+            const int slot = (wave + (int)(rid & 3u)) & 3;
 #pragma unroll
-        for (int u = 0; u < SPL; ++u) {
-            if (16 * u >= Tc) break;
-            const int jj = 16 * u + j4, i = wave * Tc + jj;
-            const bool active = (jj < Tc) && (i < Nc);
-            const int ci = min(i, Nc - 1);
-            const float b0 = l_btab[ci], b1 = l_btab[ci + 1];
-            const float px = exact_mid(exact_lerp(sx, ex, b1), exact_lerp(sx, ex, b0));
-            const float py = exact_mid(exact_lerp(sy, ey, b1), exact_lerp(sy, ey, b0));
-            const float pz = exact_mid(exact_lerp(sz, ez, b1), exact_lerp(sz, ez, b0));
-            f32x4 o;
-            bool ran;
-            uint32_t bits;
-            float wmax;
-            query_tile<MODE, false>(S, l_cand, ncand, px, py, pz, active, lane, o, ran, bits, wmax, nodbg, n_pairs, n_tiles, &n_rounds);
-            const int jm = 16 * u + lane;                       // MFMA layout: lanes < 16 hold the head of sample jm
-            if (lane < 16 && jm < Tc && wave * Tc + jm < Nc) l_ch[wave * Tc + jm] = o[3];
-            if (active && (lane & 3) == 0) { l_cbits[i] = bits; l_cwmax[i] = wmax; }
+            for (int u = 0; u < SPL; ++u) {
+                const int base = (slot * SPL + u) * 16;
+                if (base >= Nc) break;
+                const int i = base + j4;
+                const bool active = i < Nc;
+                const int ci = min(i, Nc - 1);
+                const float b0 = l_btab[ci], b1 = l_btab[ci + 1];
+                const float px = exact_mid(exact_lerp(sx, ex, b1), exact_lerp(sx, ex, b0));
+                const float py = exact_mid(exact_lerp(sy, ey, b1), exact_lerp(sy, ey, b0));
+                const float pz = exact_mid(exact_lerp(sz, ez, b1), exact_lerp(sz, ez, b0));
+                f32x4 o;
+                bool ran;
+                uint32_t bits;
+                float wmax;
+                query_tile<MODE, false>(S, l_cand, ncand, px, py, pz, active, lane, o, ran, bits, wmax, nodbg, n_pairs, n_tiles, &n_rounds);
+                if (lane < 16 && base + lane < Nc) l_ch[base + lane] = o[3];     // MFMA layout: lanes < 16 hold the sample heads
+                if (active && (lane & 3) == 0) { l_cbits[i] = bits; l_cwmax[i] = wmax; }
+            }
         }
         TMR(S, 4);
         TMR4(S, 7);
