@@ -766,8 +766,10 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
         TMR(S, 5);
         TMR4(S, 6);
 
-        // ---- S4 (wave 0, element e = 64 s + lane): compositing (rendering.py:307-335)
-        if (wave == 0) {
+        // ---- S4 (one wave, element e = 64 s + lane): compositing (rendering.py:307-335). It runs while the other waves are
+        // already in the next ray's coarse pass - on the wave that has no coarse tile there, when there is one.
+        const int s4_wave = (next_ray >= 0 && 3 * SPL * 16 >= Nc) ? ((3 - (next_ray & 3)) & 3) : 0;
+        if (wave == s4_wave) {
             float fdepth[SPL], dnext[SPL], den[SPL], cr[SPL], cg[SPL], cb[SPL], dd[SPL], cs[SPL];
 #pragma unroll
             for (int s = 0; s < SPL; ++s) {
