@@ -129,13 +129,14 @@ __device__ __forceinline__ int build_cand_list(int *list, uint32_t set, int lane
 __device__ __forceinline__ int xcc_id() {
     return (int)(__builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11)) & 0xF);   // HW_REG_XCC_ID[3:0]
 }
-constexpr int kQueueLdsInts = 4 + kQueues * kClasses;   // 2 x (list, index) slots + the staged list lengths
+constexpr int kQueueLdsInts = 4 + kQueues * kClasses + 3;   // 2 x (list, index) slots, the staged list lengths, the cursor (q, tries, class)
 struct RayQueue {                 // pop(): one thread of the workgroup; the rest: every thread
     unsigned int *heads;          // kQueues counters in the workspace header
     const uint32_t *lists;
-    int *l_q;                     // LDS: [slot][2] = (list id or -1, index in the list), then the kQueues x kClasses lengths
+    int *l_q;                     // LDS: [slot][2] = (list id or -1, index in the list), the kQueues x kClasses lengths, the cursor
     long long band;
-    int home, q, tries, cls;
+    int home;
+    int q, tries, cls;            // the cursor: lives in LDS between pops, so that any thread may do the next pop
     // every thread; ends with a barrier. The list lengths are final (written by the set-up pass of an earlier launch):
     // staged once, so that pop() is one atomic and no dependent global loads (a load from a line that is being hit by
     // atomics from the whole chip takes tens of microseconds).
@@ -146,45 +147,19 @@ struct RayQueue {                 // pop(): one thread of the workgroup; the res
         l_q = lds_ints;
         band = ws_band_size(B, n);
 #ifdef ENARF_NO_HOME_BAND
-        home = q = (int)(blockIdx.x & (kQueues - 1));
+        home = (int)(blockIdx.x & (kQueues - 1));
 #else
-        home = q = xcc_id() & (kQueues - 1);
+        home = xcc_id() & (kQueues - 1);
 #endif
-        tries = 0;
-        cls = 0;
         if (tid < kQueues * kClasses) l_q[4 + tid] = (int)wsh[kWsCountsOff + tid];
+        if (tid == 0) { l_q[4 + kQueues * kClasses] = home; l_q[5 + kQueues * kClasses] = 0; l_q[6 + kQueues * kClasses] = 0; }
         __syncthreads();
     }
-    // one thread. pop_begin() issues the atomic on the current list, pop_end() - called as late as possible, so that
-    // the atomic's round trip overlaps with work - files the result under slot and, when that list turned out to be
-    // drained, goes on to the next ones. List = -1 once every list is drained.
-    unsigned int pend_j;
-    int pend_l;
-    __device__ __forceinline__ void pop_begin() {
-        pend_l = -1;
-        pend_j = 0;
-        if (cls < kClasses && tries < kQueues) {
-            const int l = q * kClasses + cls;
-            if (l_q[4 + l] != 0) {
-                pend_l = l;
-                pend_j = atomicAdd(heads + l * kWsHeadStride, 1u);
-            }
-        }
-    }
-    __device__ __forceinline__ void pop_end(int slot) {
-        if (pend_l >= 0 && pend_j < (unsigned int)l_q[4 + pend_l]) {
-            l_q[2 * slot] = pend_l;
-            l_q[2 * slot + 1] = (int)pend_j;
-            return;
-        }
-        if (cls < kClasses) {   // the speculated list is empty or drained: move on
-            q = (q + 1) & (kQueues - 1);
-            tries += 1;
-        }
-        pop(slot);
-    }
+    // one thread (any): next (list, index) into slot, list = -1 once every list is drained
     __device__ __forceinline__ void pop(int slot) {
         int lid = -1, idx = 0;
+        int *cur = l_q + 4 + kQueues * kClasses;
+        q = cur[0]; tries = cur[1]; cls = cur[2];
         while (cls < kClasses) {
             while (tries < kQueues) {
                 const int l = q * kClasses + cls;
@@ -203,6 +178,7 @@ struct RayQueue {                 // pop(): one thread of the workgroup; the res
         }
         l_q[2 * slot] = lid;
         l_q[2 * slot + 1] = idx;
+        cur[0] = q; cur[1] = tries; cur[2] = cls;
     }
     // every thread, after a barrier that follows pop(slot): the ray id (b * n + ray), or -1
     __device__ __forceinline__ long long get(int slot) const {

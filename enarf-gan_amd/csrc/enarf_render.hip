@@ -4,9 +4,6 @@
 #include "enarf_host.h"
 #include <cstdlib>
 
-#ifndef ENARF_SPLIT_POP
-#define ENARF_SPLIT_POP 0
-#endif
 #ifndef ENARF_PREFETCH_REC
 #define ENARF_PREFETCH_REC 0
 #endif
@@ -574,12 +571,11 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
 #if ENARF_TIMERS == 3
         { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); if (now - ray_t0 > ray_max && n_rays) ray_max = now - ray_t0; ray_t0 = now; }
 #endif
-#if ENARF_SPLIT_POP
-        if (tid == 0) rq.pop_begin();      // next entry: the atomic flies during S1; filed before the S1 barrier
-#else
-        if (tid == 0) rq.pop(qslot ^ 1);   // next entry; read after the S1 barrier
-#endif
         const uint32_t rid = (uint32_t)cur;
+        // next entry (read after the S1 barrier): popped by the wave that has no coarse tile in this ray, when there is
+        // one - the atomic's round trip then costs nothing
+        const int spare_wave = (3 * SPL * 16 >= Nc) ? ((3 - (int)(rid & 3u)) & 3) : 0;
+        if (wave == spare_wave && lane == 0) rq.pop(qslot ^ 1);
         const int nb = (int)(rid / (uint32_t)n), ray = (int)(rid - (uint32_t)nb * (uint32_t)n);
         if (nb != b) {   // next image: restage its MLP pack and part frames (the lists are in image order, so this is rare)
             b = nb;
@@ -633,9 +629,6 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
         }
         TMR(S, 4);
         TMR4(S, 7);
-#if ENARF_SPLIT_POP
-        if (tid == 0) rq.pop_end(qslot ^ 1);
-#endif
         __syncthreads();
         TMR(S, 5);
         TMR4(S, 6);
