@@ -129,20 +129,26 @@ __device__ __forceinline__ int build_cand_list(int *list, uint32_t set, int lane
 __device__ __forceinline__ int xcc_id() {
     return (int)(__builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11)) & 0xF);   // HW_REG_XCC_ID[3:0]
 }
-constexpr int kQueueLdsInts = 4 + kQueues * kClasses + 3;   // 2 x (list, index) slots, the staged list lengths, the cursor (q, tries, class)
-struct RayQueue {                 // pop(): one thread of the workgroup; the rest: every thread
-    unsigned int *heads;          // kQueues counters in the workspace header
+// LDS of the queue (ints, 16-byte aligned): 2 slots x [ray id, -, -, -, RayRec (8)], the kQueues x kClasses list lengths,
+// the cursor (band, tries, class)
+constexpr int kQSlotInts = 12;
+constexpr int kQCountsOff = 2 * kQSlotInts;
+constexpr int kQCursorOff = kQCountsOff + kQueues * kClasses;
+constexpr int kQueueLdsInts = kQCursorOff + 3;
+struct RayQueue {
+    unsigned int *heads;          // queue heads in the workspace header
     const uint32_t *lists;
-    int *l_q;                     // LDS: [slot][2] = (list id or -1, index in the list), the kQueues x kClasses lengths, the cursor
+    const RayRec *recs;
+    int *l_q;
     long long band;
     int home;
-    int q, tries, cls;            // the cursor: lives in LDS between pops, so that any thread may do the next pop
     // every thread; ends with a barrier. The list lengths are final (written by the set-up pass of an earlier launch):
-    // staged once, so that pop() is one atomic and no dependent global loads (a load from a line that is being hit by
-    // atomics from the whole chip takes tens of microseconds).
+    // staged once, so that a pop never loads from the header (a load from a line that is being hit by atomics from the
+    // whole chip takes tens of microseconds).
     __device__ __forceinline__ void init(void *workspace, int B, int n, int *lds_ints, int tid) {
         unsigned int *wsh = reinterpret_cast<unsigned int *>(workspace);
         heads = wsh + kWsHeadsOff;
+        recs = reinterpret_cast<const RayRec *>(reinterpret_cast<const char *>(workspace) + ws_records_off());
         lists = reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(workspace) + ws_list_off((long long)B * n));
         l_q = lds_ints;
         band = ws_band_size(B, n);
@@ -151,19 +157,21 @@ struct RayQueue {                 // pop(): one thread of the workgroup; the res
 #else
         home = xcc_id() & (kQueues - 1);
 #endif
-        if (tid < kQueues * kClasses) l_q[4 + tid] = (int)wsh[kWsCountsOff + tid];
-        if (tid == 0) { l_q[4 + kQueues * kClasses] = home; l_q[5 + kQueues * kClasses] = 0; l_q[6 + kQueues * kClasses] = 0; }
+        if (tid < kQueues * kClasses) l_q[kQCountsOff + tid] = (int)wsh[kWsCountsOff + tid];
+        if (tid == 0) { l_q[kQCursorOff] = home; l_q[kQCursorOff + 1] = 0; l_q[kQCursorOff + 2] = 0; }
         __syncthreads();
     }
-    // one thread (any): next (list, index) into slot, list = -1 once every list is drained
+    // ONE thread (any - the cursor lives in LDS): take the next ray off the queues and leave its id and its set-up
+    // record in slot; id -1 once every list is drained. The whole dependent chain (atomic -> list entry -> record) runs
+    // here, on a wave that has nothing else to do, so the other waves find the record in LDS.
     __device__ __forceinline__ void pop(int slot) {
         int lid = -1, idx = 0;
-        int *cur = l_q + 4 + kQueues * kClasses;
-        q = cur[0]; tries = cur[1]; cls = cur[2];
+        int *cur = l_q + kQCursorOff;
+        int q = cur[0], tries = cur[1], cls = cur[2];
         while (cls < kClasses) {
             while (tries < kQueues) {
                 const int l = q * kClasses + cls;
-                const unsigned int len = (unsigned int)l_q[4 + l];
+                const unsigned int len = (unsigned int)l_q[kQCountsOff + l];
                 if (len != 0) {
                     const unsigned int j = atomicAdd(heads + l * kWsHeadStride, 1u);
                     if (j < len) { lid = l; idx = (int)j; break; }
@@ -176,15 +184,17 @@ struct RayQueue {                 // pop(): one thread of the workgroup; the res
             q = home;
             tries = 0;
         }
-        l_q[2 * slot] = lid;
-        l_q[2 * slot + 1] = idx;
         cur[0] = q; cur[1] = tries; cur[2] = cls;
+        int *d = l_q + slot * kQSlotInts;
+        if (lid < 0) { d[0] = -1; return; }
+        const uint32_t rid = lists[(size_t)lid * (size_t)band + (size_t)idx];
+        const RayRec r = recs[rid];
+        d[0] = (int)rid;
+        *reinterpret_cast<RayRec *>(d + 4) = r;
     }
-    // every thread, after a barrier that follows pop(slot): the ray id (b * n + ray), or -1
-    __device__ __forceinline__ long long get(int slot) const {
-        const int lid = l_q[2 * slot];
-        return lid < 0 ? -1ll : (long long)lists[(size_t)lid * (size_t)band + (size_t)l_q[2 * slot + 1]];
-    }
+    // every thread, after a barrier that follows pop(slot)
+    __device__ __forceinline__ int get(int slot) const { return l_q[slot * kQSlotInts]; }
+    __device__ __forceinline__ RayRec rec(int slot) const { return *reinterpret_cast<const RayRec *>(l_q + slot * kQSlotInts + 4); }
 };
 
 

@@ -4,9 +4,6 @@
 #include "enarf_host.h"
 #include <cstdlib>
 
-#ifndef ENARF_PREFETCH_REC
-#define ENARF_PREFETCH_REC 0
-#endif
 #ifndef ENARF_RENDER_WAVES_PER_SIMD
 #define ENARF_RENDER_WAVES_PER_SIMD 3
 #endif
@@ -522,7 +519,6 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
     // moment the whole chip works on a window of a few image rows, whose tri-plane footprint stays in every XCD's L2.
     const int P = a.P, Nc = a.Nc, Nf = a.Nf, n = a.n;
     RayQueue rq;                                            // thread 0's view of the XCD-affine queues
-    const RayRec *recs = reinterpret_cast<const RayRec *>(reinterpret_cast<const char *>(a.workspace) + ws_records_off());
 
 #if ENARF_TIMERS == 3   // workgroup start / end on the 100 MHz wall clock: how much of the launch is tail
     const unsigned long long wg_t0 = __builtin_amdgcn_s_memrealtime();
@@ -533,7 +529,7 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
     rq.init(a.workspace, a.B, n, l_q, tid);
     if (tid == 0) rq.pop(0);
     __syncthreads();
-    int cur = (int)rq.get(0);
+    int cur = rq.get(0);
     if (cur < 0) return;                      // uniform: every queue is already drained
     int b = (int)((uint32_t)cur / (uint32_t)n);
     stage_common<MODE>(lds, S, scratch, reinterpret_cast<const char *>(a.mlp_pack) + (size_t)b * kPackBytes,
@@ -564,9 +560,6 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
 #if ENARF_TIMERS == 3
     unsigned long long ray_t0 = wg_t0, ray_max = 0;
 #endif
-#if ENARF_PREFETCH_REC
-    RayRec nrec = recs[cur];
-#endif
     while (cur >= 0) {
 #if ENARF_TIMERS == 3
         { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); if (now - ray_t0 > ray_max && n_rays) ray_max = now - ray_t0; ray_t0 = now; }
@@ -587,12 +580,8 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
             __syncthreads();
         }
         // depth range, candidate parts and ray direction K^-1 [u v w] (rendering.py:26-38): from the set-up pre-pass,
-        // fetched while the previous ray was still being marched
-#if ENARF_PREFETCH_REC
-        const RayRec rec = nrec;
-#else
-        const RayRec rec = recs[rid];
-#endif
+        // left in LDS by the pop
+        const RayRec rec = rq.rec(qslot);
         const float dx = rec.dx, dy = rec.dy, dz = rec.dz;
         const float dmin = rec.dmin, dmax = rec.dmax;
         if (wave == 0) n_rays += 1;
@@ -632,7 +621,7 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
         __syncthreads();
         TMR(S, 5);
         TMR4(S, 6);
-        const int next_ray = (int)rq.get(qslot ^ 1);
+        const int next_ray = rq.get(qslot ^ 1);
         qslot ^= 1;
 
         // ---- S2 (every wave, element e = 64 s + lane): weights (rendering.py:180-184), smoothing (:187-190), bins (:192-197)
@@ -727,9 +716,6 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
             }
         }
 
-#if ENARF_PREFETCH_REC
-        nrec = recs[max(next_ray, 0)];     // the list entry has arrived by now; the record flies during S3 / S4
-#endif
         TMR(S, 6);
         TMR4(S, 2);
         // ---- S3: fine pass, wave w owns samples [w Tf, (w+1) Tf); the last sample only closes the last interval

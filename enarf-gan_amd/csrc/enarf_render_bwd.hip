@@ -76,7 +76,6 @@ __global__ __launch_bounds__(256, kBwdWavesPerSimd) void render_bwd_kernel(const
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int P = a.P, Nf = a.Nf, n = a.n;
     RayQueue rq;
-    const RayRec *recs = reinterpret_cast<const RayRec *>(reinterpret_cast<const char *>(a.workspace) + ws_records_off());
     // LDS: [fp32 weights PK_B1][bias 144][transposed PKT_FLOATS][parts][canon][scratch]
     float *l_w = lds, *l_bias = l_w + PK_B1, *l_wt = l_bias + 144, *l_parts = l_wt + PKT_FLOATS;
     float *l_canon = l_parts + P * kLdsPartStride, *scratch = l_canon + P * kLdsCanonStride;
@@ -84,7 +83,7 @@ __global__ __launch_bounds__(256, kBwdWavesPerSimd) void render_bwd_kernel(const
     rq.init(a.workspace, a.B, n, l_q, tid);
     if (tid == 0) rq.pop(0);
     __syncthreads();
-    int cur = (int)rq.get(0);
+    int cur = rq.get(0);
     if (cur < 0) return;
     int b = -1;
     QueryCtx S;
@@ -125,7 +124,7 @@ __global__ __launch_bounds__(256, kBwdWavesPerSimd) void render_bwd_kernel(const
             gmask = a.grad_mask_planes + (size_t)b * a.grad_mask_batch_stride;
             __syncthreads();
         }
-        const RayRec rec = recs[rid];      // depth range, candidates and ray direction from the set-up pass
+        const RayRec rec = rq.rec(qslot);  // depth range, candidates and ray direction from the set-up pass (left in LDS by the pop)
         const float dx_ = rec.dx, dy_ = rec.dy, dz_ = rec.dz;
         const float dmin = rec.dmin, dmax = rec.dmax;
         const int ncand = build_cand_list(l_cand, rec.cand, lane);
@@ -209,7 +208,7 @@ __global__ __launch_bounds__(256, kBwdWavesPerSimd) void render_bwd_kernel(const
         }
         if ((j4 < Tf) && (i < Nf) && g4 == 0) l_fbits[i] = active ? bits : 0u;
         __syncthreads();
-        const int next_ray = (int)rq.get(qslot ^ 1);
+        const int next_ray = rq.get(qslot ^ 1);
         qslot ^= 1;
 
         // ---- F2 (wave 0, lane = sample): compositing backward -> dL/dz3
