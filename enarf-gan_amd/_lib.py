@@ -92,6 +92,7 @@ SIGNATURES = {
     "enarf_abi_version": (C.c_int, []),
     "enarf_last_error": (C.c_char_p, []),
     "enarf_triplane_sample_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
+    "enarf_triplane_sample_bwd_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
     "enarf_triplane_sample_fwd": (C.c_int, [_f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_longlong,
                                             C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "enarf_triplane_sample_bwd": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -218,6 +218,77 @@ __global__ __launch_bounds__(256) void sample_bwd_direct(const float *__restrict
     }
 }
 
+// ---- fast backward (bilinear, C = 32, caller's workspace): ONE LANE PER CHANNEL ----------------------------------------
+// 32 lanes per point, two points per wave instruction: every atomic instruction adds into two whole 128-B lines of a
+// channel-last gradient buffer (scattered 4-byte atomics into the NCHW planes - the direct kernel - run ~7x slower), and
+// every read of the forward input for grad_grid is one whole line of the channel-last copy. grad_out is staged through
+// LDS so that its (channel-major) rows are read coalesced. gcl is folded back into NCHW by enarf_triplane_unpack_add.
+__global__ __launch_bounds__(256) void sample_bwd_cl32(const float *__restrict__ gout, const float *__restrict__ cl_in,
+                                                       const float *__restrict__ grid, float *__restrict__ gcl,
+                                                       float *__restrict__ ggrid, int H, int W, long long n, SamplerCfg cfg) {
+    constexpr int C = 32;
+    __shared__ float tile[C * 65];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, half = lane >> 5;
+    const int b = blockIdx.y;
+    const long long i0 = (long long)blockIdx.x * 64;
+    {
+        const int pj = tid & 63;
+        const bool ok = i0 + pj < n;
+        for (int cc = tid >> 6; cc < C; cc += 4)
+            tile[cc * 65 + pj] = ok ? gout[((size_t)b * C + cc) * n + i0 + pj] : 0.0f;
+    }
+    __syncthreads();
+    const size_t hw = (size_t)H * W;
+    for (int it = 0; it < 8; ++it) {
+        const int j = wave * 16 + 2 * it + half;
+        const long long i = i0 + j;
+        const bool valid = i < n;
+        const float *gp = grid + ((size_t)b * n + (valid ? i : 0)) * 3;
+        const float c3[3] = {gp[0], gp[1], gp[2]};
+        const float gO = tile[c * 65 + j];
+        float gg[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            float gxm, gym;
+            const float ix = gs_source_index(c3[p], W, cfg, gxm);
+            const float iy = gs_source_index(c3[(p + 1) % 3], H, cfg, gym);
+            const Tap2D t = gs_taps(ix, iy, H, W);
+            const float ax1 = ix - t.fx, ax0 = (t.fx + 1.0f) - ix, ay1 = iy - t.fy, ay0 = (t.fy + 1.0f) - iy;
+            const size_t base = (((size_t)b * 3 + p) * hw) * C + c;
+            if (gcl && valid) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (t.inb[k]) atomicAdd(gcl + base + (size_t)t.o[k] * C, t.w[k] * gO);
+            }
+            if (ggrid && valid) {   // kernel.cu:170-202
+                float gix = 0.0f, giy = 0.0f;
+                if (t.inb[0]) { const float v = cl_in[base + (size_t)t.o[0] * C]; gix -= v * ay0 * gO; giy -= v * ax0 * gO; }
+                if (t.inb[1]) { const float v = cl_in[base + (size_t)t.o[1] * C]; gix += v * ay0 * gO; giy -= v * ax1 * gO; }
+                if (t.inb[2]) { const float v = cl_in[base + (size_t)t.o[2] * C]; gix -= v * ay1 * gO; giy += v * ax0 * gO; }
+                if (t.inb[3]) { const float v = cl_in[base + (size_t)t.o[3] * C]; gix += v * ay1 * gO; giy += v * ax1 * gO; }
+                gg[p] += gxm * gix;
+                gg[(p + 1) % 3] += gym * giy;
+            }
+        }
+        if (ggrid) {   // sum over the 32 channel lanes of each point: row scans, then row 0 -> 1 and row 2 -> 3
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                float v = gg[d];
+                v += dpp_f<0x111, 0xF>(v);
+                v += dpp_f<0x112, 0xF>(v);
+                v += dpp_f<0x114, 0xF>(v);
+                v += dpp_f<0x118, 0xF>(v);
+                v += dpp_f<0x142, 0xA>(v);
+                gg[d] = v;
+            }
+            if (valid && c == 31) {
+                float *o = ggrid + ((size_t)b * n + i) * 3;
+                o[0] = gg[0]; o[1] = gg[1]; o[2] = gg[2];
+            }
+        }
+    }
+}
+
 }  // namespace enarf
 
 using namespace enarf;
@@ -238,6 +309,11 @@ static bool cl_supported(int C) { return C == 8 || C == 16 || C == 32 || C == 64
 extern "C" size_t enarf_triplane_sample_workspace_bytes(int B, int C, int H, int W) {
     if (!cl_supported(C) || B <= 0 || H <= 0 || W <= 0) return 0;
     return (size_t)B * 3 * C * H * W * sizeof(float);
+}
+// backward fast path: channel-last copy of the input (for grad_grid) + channel-last gradient accumulator
+extern "C" size_t enarf_triplane_sample_bwd_workspace_bytes(int B, int C, int H, int W) {
+    if (C != ENARF_FEAT_DIM || B <= 0 || H <= 0 || W <= 0) return 0;
+    return 2 * (size_t)B * 3 * C * H * W * sizeof(float);
 }
 
 template <int C>
@@ -288,10 +364,23 @@ extern "C" int enarf_triplane_sample_fwd(const float *input, const float *grid, 
 extern "C" int enarf_triplane_sample_bwd(const float *grad_out, const float *input, const float *grid, float *grad_input,
                                          float *grad_grid, int B, int C, int H, int W, long long n_pts, int interp, int pad,
                                          int align_corners, void *workspace, enarf_stream_t stream) {
-    (void)workspace;
     if (int rc = check_sampler("enarf_triplane_sample_bwd", grad_out, input, grid, B, C, H, W, n_pts, interp, pad)) return rc;
     if (n_pts == 0 || (!grad_input && !grad_grid)) return 0;
     const SamplerCfg cfg{interp, pad, align_corners ? 1 : 0};
+    if (workspace && interp == ENARF_INTERP_BILINEAR && C == ENARF_FEAT_DIM && H <= 65535 && B * 3 <= 65535) {
+        hipStream_t st = (hipStream_t)stream;
+        const size_t plane_floats = (size_t)B * 3 * C * H * W;
+        float *cl_in = reinterpret_cast<float *>(workspace), *gcl = cl_in + plane_floats;
+        if (grad_grid) launch_pack<ENARF_FEAT_DIM>(input, cl_in, B, 3 * C, H, W, st);
+        if (grad_input) {
+            hipError_t e = hipMemsetAsync(gcl, 0, plane_floats * sizeof(float), st);
+            if (e != hipSuccess) return host::fail((int)e, "enarf_triplane_sample_bwd: hipMemsetAsync failed: %s", hipGetErrorString(e));
+        }
+        hipLaunchKernelGGL(sample_bwd_cl32, dim3((unsigned)((n_pts + 63) / 64), B), dim3(256), 0, st, grad_out,
+                           grad_grid ? cl_in : nullptr, grid, grad_input ? gcl : nullptr, grad_grid, H, W, n_pts, cfg);
+        if (int rc = host::check_launch("enarf_triplane_sample_bwd")) return rc;
+        return grad_input ? enarf_triplane_unpack_add(gcl, grad_input, B, 3 * C, H, W, stream) : 0;
+    }
     hipLaunchKernelGGL(sample_bwd_direct, dim3((unsigned)((n_pts + 255) / 256), B), dim3(256), 0, (hipStream_t)stream,
                        grad_out, input, grid, grad_input, grad_grid, C, H, W, n_pts, cfg);
     return host::check_launch("enarf_triplane_sample_bwd");

@@ -65,7 +65,7 @@ def triplane_sample_fwd(inp: torch.Tensor, grid: torch.Tensor, mode: int = 0, pa
 
 
 def triplane_sample_bwd(grad_out: torch.Tensor, inp: torch.Tensor, grid: torch.Tensor, mode: int, padding_mode: int,
-                        align_corners: bool, need_input: bool, need_grid: bool
+                        align_corners: bool, need_input: bool, need_grid: bool, use_workspace: bool = True
                         ) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
     """cuda_extension/TriplaneSampler.cpp:26-52; returns (grad_input, grad_grid), None where not needed."""
     lib = _lib.load()
@@ -76,8 +76,13 @@ def triplane_sample_bwd(grad_out: torch.Tensor, inp: torch.Tensor, grid: torch.T
     h, w = grid.shape[1], grid.shape[2]
     gi = torch.zeros_like(inp) if need_input else None
     gg = torch.empty_like(grid) if need_grid else None
+    ws = None
+    if use_workspace:
+        nbytes = lib.enarf_triplane_sample_bwd_workspace_bytes(B, C3 // 3, H, W)
+        if nbytes:
+            ws = torch.empty(nbytes // 4, dtype=torch.float32, device=inp.device)
     rc = lib.enarf_triplane_sample_bwd(_p(grad_out), _p(inp), _p(grid), _p(gi), _p(gg), B, C3 // 3, H, W, h * w,
-                                       mode, padding_mode, int(bool(align_corners)), None, _stream(inp.device))
+                                       mode, padding_mode, int(bool(align_corners)), _p(ws), _stream(inp.device))
     _lib.check(rc, "enarf_triplane_sample_bwd")
     return gi, gg
 

@@ -62,9 +62,13 @@ const char *enarf_last_error(void);
  * `workspace` (device, enarf_triplane_sample_workspace_bytes() bytes, may be NULL) lets the operator
  * re-lay the planes channel-last once per call; without it a slower direct-NCHW kernel runs.
  * Backward: grad_input (same shape as input) must be zero-filled by the caller, as in the reference
- * (TriplaneSampler.cpp:33-39); either grad pointer may be NULL (= output_mask false).
+ * (TriplaneSampler.cpp:33-39); either grad pointer may be NULL (= output_mask false). With a workspace of
+ * enarf_triplane_sample_bwd_workspace_bytes() bytes (non-zero for C = 32, used in bilinear mode) the gradient is
+ * accumulated channel-last with whole-line atomics and folded back into grad_input; without it the direct kernel
+ * scatters 4-byte atomics into the NCHW planes (several times slower).
  * --------------------------------------------------------------------------------------------- */
 size_t enarf_triplane_sample_workspace_bytes(int B, int C, int H, int W);
+size_t enarf_triplane_sample_bwd_workspace_bytes(int B, int C, int H, int W);
 int enarf_triplane_sample_fwd(const float *input, const float *grid, float *out,
                               int B, int C, int H, int W, long long n_pts,
                               int interpolation_mode, int padding_mode, int align_corners,

@@ -96,6 +96,36 @@ def test_sampler_padding_modes_vs_torch(ops, pad, align):
         assert_close(_cpu(out), ref, f"pad={mode} align={align}", 1e-5)
 
 
+@pytest.mark.parametrize("pad,align", [(0, False), (1, False), (2, True)])
+def test_sampler_backward_fast_path_vs_direct_and_autograd(ops, pad, align):
+    """C = 32 backward through the channel-last whole-line-atomics kernel (caller's workspace) against the direct
+    NCHW kernel and against torch autograd through three F.grid_sample calls; ragged point count, batch 2, points
+    outside [-1, 1]."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(21)
+    C = 32
+    inp = torch.randn(2, 3 * C, 24, 40, generator=g)
+    grid = torch.rand(2, 1000 + 37, 1, 3, generator=g) * 2.4 - 1.2
+    go = torch.randn(2, C, 1000 + 37, 1, generator=g)
+    mode = ["zeros", "border", "reflection"][pad]
+    x, q = inp.clone().requires_grad_(True), grid.clone().requires_grad_(True)
+    ref = 0
+    for p in range(3):
+        g2 = torch.stack([q[..., p], q[..., (p + 1) % 3]], dim=-1)
+        ref = ref + F.grid_sample(x[:, p * C:(p + 1) * C], g2, padding_mode=mode, align_corners=align)
+    ref.backward(go)
+    fast = ops.triplane_sample_bwd(go.cuda(), inp.cuda(), grid.cuda(), 0, pad, align, True, True, use_workspace=True)
+    slow = ops.triplane_sample_bwd(go.cuda(), inp.cuda(), grid.cuda(), 0, pad, align, True, True, use_workspace=False)
+    for name, (gi, gg) in (("fast", fast), ("direct", slow)):
+        assert_close(_cpu(gi), x.grad, f"{name} grad_input pad={mode}", 1e-5)
+        assert_close(_cpu(gg), q.grad, f"{name} grad_grid pad={mode}", 1e-5)
+    only_grid = ops.triplane_sample_bwd(go.cuda(), inp.cuda(), grid.cuda(), 0, pad, align, False, True)
+    assert only_grid[0] is None and torch.equal(only_grid[1], fast[1])
+    only_in = ops.triplane_sample_bwd(go.cuda(), inp.cuda(), grid.cuda(), 0, pad, align, True, False)
+    assert only_in[1] is None
+    assert_close(_cpu(only_in[0]), x.grad, "grad_input alone", 1e-5)
+
+
 def test_sampler_nearest_last_plane_wins(ops):
     g = torch.Generator().manual_seed(4)
     C = 4

@@ -18,7 +18,8 @@ grid = (torch.rand(1, N, 1, 3, device=dev, generator=g) * 2 - 1).contiguous()
 go = torch.randn(1, 32, N, 1, device=dev, generator=g)
 for name, fn in (("fwd channel-last (pack + gather)", lambda: ops.triplane_sample_fwd(inp, grid, use_workspace=True)),
                  ("fwd direct NCHW", lambda: ops.triplane_sample_fwd(inp, grid, use_workspace=False)),
-                 ("bwd direct NCHW (grad input + grid)", lambda: ops.triplane_sample_bwd(go, inp, grid, 0, 0, False, True, True))):
+                 ("bwd channel-last atomics (input + grid)", lambda: ops.triplane_sample_bwd(go, inp, grid, 0, 0, False, True, True)),
+                 ("bwd direct NCHW (grad input + grid)", lambda: ops.triplane_sample_bwd(go, inp, grid, 0, 0, False, True, True, use_workspace=False))):
     for _ in range(2):
         fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
