@@ -90,13 +90,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU path in enarf_gan_amd")
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU; a rehearsal with more ranks than GPUs (ENARF_BENCH_BACKEND=gloo on a 1-GPU box) wraps around
+    dev = torch.device("cuda", local_rank % torch.cuda.device_count())
     torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("ENARF_BENCH_BACKEND", "nccl")     # nccl = RCCL over xGMI
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from enarf_gan_amd import ops, synth
     from oracle import enarf_oracle as O   # only for the canonical-pose buffers of the synthetic scene and the cpu_baseline leg
