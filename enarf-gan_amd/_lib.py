@@ -79,6 +79,16 @@ class RenderBwdArgs(C.Structure):
     ]
 
 
+class WeightGradArgs(C.Structure):
+    _fields_ = [
+        ("B", C.c_int),
+        ("rows_x", _f32p), ("rows_h1", _f32p), ("rows_h2", _f32p), ("rows_dz1", _f32p), ("rows_dz2", _f32p),
+        ("rows_dz3", _f32p), ("rows_per_image", C.c_longlong), ("row_blocks", _f32p),
+        ("dW1", _f32p), ("dW2", _f32p), ("dW3", _f32p), ("db1", _f32p), ("db2", _f32p), ("db3", _f32p),
+        ("workspace", _f32p),
+    ]
+
+
 class PrepareBwdArgs(C.Structure):
     _fields_ = [
         ("B", C.c_int), ("style_dim", C.c_int), ("z_rend", _f32p),
@@ -106,6 +116,8 @@ SIGNATURES = {
     "enarf_render_fwd": (C.c_int, [C.POINTER(RenderArgs), C.c_void_p]),
     "enarf_render_step_fwd": (C.c_int, [C.POINTER(PrepareArgs), _f32p, _f32p, C.c_int, C.c_int, C.POINTER(RenderArgs),
                                         C.c_int, C.c_void_p]),
+    "enarf_weight_grad_workspace_bytes": (C.c_size_t, [C.c_int, C.c_longlong]),
+    "enarf_weight_grad": (C.c_int, [C.POINTER(WeightGradArgs), C.c_void_p]),
     "enarf_render_bwd_rows_per_image": (C.c_longlong, [C.c_int, C.c_int]),
     "enarf_render_bwd": (C.c_int, [C.POINTER(RenderBwdArgs), C.c_void_p]),
     "enarf_prepare_bwd": (C.c_int, [C.POINTER(PrepareBwdArgs), C.c_void_p]),

@@ -354,6 +354,128 @@ __global__ __launch_bounds__(256) void unpack_add_kernel(const float *__restrict
         if (xb + x < W) dst[(size_t)c * H * W + xb + x] += tile[c * 65 + x];
 }
 
+// ---- weight gradients from the exported rows: dW_l = dZ_l^T H_{l-1}, db_l = sum_rows dZ_l ------------------------------
+// A reduction over ~0.5 M rows with 64 x 64 (64 x 32, 4 x 64) outputs: a library GEMM picks a tile shape made for big
+// outputs and spends 0.8 ms on each; here every WAVE streams its own chunk of rows through v_mfma_f32_16x16x4_f32
+// (4 rows per step, operands straight from coalesced 16-B loads: lane l reads row l/16, columns 4(l%16)..+3, and
+// register r of that load is the operand block "columns 4i + r" - a permutation of the output that the second kernel
+// undoes), keeps all three products in 112 accumulator registers, and stores its partial; a second kernel sums the
+// partials. No atomics: the result is deterministic.
+constexpr int kWgRowsPerWave = 1024;
+constexpr int kWgAcc2 = 0, kWgAcc1 = 16 * 256, kWgAcc3 = kWgAcc1 + 8 * 256, kWgSum2 = kWgAcc3 + 4 * 256;
+constexpr int kWgSum1 = kWgSum2 + 256, kWgSum3 = kWgSum1 + 256, kWgPartial = kWgSum3 + 64;      // floats per wave chunk
+
+struct WeightGradParams {
+    const float *x, *h1, *h2, *dz1, *dz2, *dz3;
+    long long rows_per_image;
+    const unsigned int *row_blocks;
+    float *partial;            // [B][chunks][kWgPartial]
+    int chunks;                // wave chunks per image the launch covers
+    float *dW1, *dW2, *dW3, *db1, *db2, *db3;
+};
+
+__global__ __launch_bounds__(256) void weight_grad_partial_kernel(const WeightGradParams p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.y;
+    const int chunk = blockIdx.x * 4 + wave;
+    const long long count = (long long)p.row_blocks[b] * 16;
+    const long long r0 = (long long)chunk * kWgRowsPerWave;
+    if (chunk >= p.chunks || r0 >= count) return;             // wave-uniform
+    const long long r1 = (r0 + kWgRowsPerWave < count) ? r0 + kWgRowsPerWave : count;   // multiple of 16
+    const int kg = lane >> 4, i16 = lane & 15;
+    const size_t base = (size_t)b * p.rows_per_image;
+    f32x4 acc2[16], acc1[8], acc3[4];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc2[t] = f32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc1[t] = f32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc3[t] = f32x4{0, 0, 0, 0};
+    f32x4 s2 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0};
+    float s3 = 0.0f;
+    for (long long r = r0; r < r1; r += 4) {
+        const size_t row = base + (size_t)r + kg;
+        const f32x4 vdz2 = *reinterpret_cast<const f32x4 *>(p.dz2 + row * 64 + 4 * i16);
+        const f32x4 vh1 = *reinterpret_cast<const f32x4 *>(p.h1 + row * 64 + 4 * i16);
+        const f32x4 vdz1 = *reinterpret_cast<const f32x4 *>(p.dz1 + row * 64 + 4 * i16);
+        const f32x4 vh2 = *reinterpret_cast<const f32x4 *>(p.h2 + row * 64 + 4 * i16);
+        const float2 vx = *reinterpret_cast<const float2 *>(p.x + row * 32 + 2 * i16);
+        const float vdz3 = (i16 < 4) ? p.dz3[row * 4 + i16] : 0.0f;
+#pragma unroll
+        for (int ra = 0; ra < 4; ++ra) {
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb)
+                acc2[ra * 4 + rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(vdz2[ra], vh1[rb], acc2[ra * 4 + rb], 0, 0, 0);
+            acc1[ra * 2 + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(vdz1[ra], vx.x, acc1[ra * 2 + 0], 0, 0, 0);
+            acc1[ra * 2 + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(vdz1[ra], vx.y, acc1[ra * 2 + 1], 0, 0, 0);
+            acc3[ra] = __builtin_amdgcn_mfma_f32_16x16x4f32(vdz3, vh2[ra], acc3[ra], 0, 0, 0);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { s2[c] += vdz2[c]; s1[c] += vdz1[c]; }
+        s3 += vdz3;
+    }
+    float *out = p.partial + ((size_t)b * p.chunks + chunk) * kWgPartial;
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) out[kWgAcc2 + (t * 4 + q) * 64 + lane] = acc2[t][q];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) out[kWgAcc1 + (t * 4 + q) * 64 + lane] = acc1[t][q];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) out[kWgAcc3 + (t * 4 + q) * 64 + lane] = acc3[t][q];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { out[kWgSum2 + c * 64 + lane] = s2[c]; out[kWgSum1 + c * 64 + lane] = s1[c]; }
+    out[kWgSum3 + lane] = s3;
+}
+
+// one thread per output element: sums the wave partials that hold it (and undoes the operand permutation)
+__global__ __launch_bounds__(256) void weight_grad_reduce_kernel(const WeightGradParams p) {
+    const int e = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    constexpr int N2 = 64 * 64, N1 = 64 * 32, N3 = 4 * 64, NB = 64 + 64 + 4;
+    if (e >= N2 + N1 + N3 + NB) return;
+    const long long count = (long long)p.row_blocks[b] * 16;
+    const int valid = (int)((count + kWgRowsPerWave - 1) / kWgRowsPerWave);
+    const int nch = valid < p.chunks ? valid : p.chunks;
+    int idx[4], nidx = 1;
+    float *dst;
+    if (e < N2) {                       // dW2[m][c]: tile (m%4, c%4), register (m/4)%4, lane 16 (m/16) + c/4
+        const int m = e / 64, c = e % 64;
+        idx[0] = kWgAcc2 + (((m & 3) * 4 + (c & 3)) * 4 + ((m >> 2) & 3)) * 64 + 16 * (m >> 4) + (c >> 2);
+        dst = p.dW2 + (size_t)b * N2 + e;
+    } else if (e < N2 + N1) {           // dW1[m][c]: tile (m%4, c%2), lane 16 (m/16) + c/2
+        const int f = e - N2, m = f / 32, c = f % 32;
+        idx[0] = kWgAcc1 + (((m & 3) * 2 + (c & 1)) * 4 + ((m >> 2) & 3)) * 64 + 16 * (m >> 4) + (c >> 1);
+        dst = p.dW1 + (size_t)b * N1 + f;
+    } else if (e < N2 + N1 + N3) {      // dW3[o][c]: tile c%4, register o, lanes 0..15
+        const int f = e - N2 - N1, o = f / 64, c = f % 64;
+        idx[0] = kWgAcc3 + ((c & 3) * 4 + o) * 64 + (c >> 2);
+        dst = p.dW3 + (size_t)b * N3 + f;
+    } else {                            // biases: column sums held by the four k-groups of lanes
+        const int f = e - N2 - N1 - N3;
+        nidx = 4;
+        if (f < 64) {
+            for (int g = 0; g < 4; ++g) idx[g] = kWgSum1 + (f & 3) * 64 + 16 * g + (f >> 2);
+            dst = p.db1 + (size_t)b * 64 + f;
+        } else if (f < 128) {
+            const int c = f - 64;
+            for (int g = 0; g < 4; ++g) idx[g] = kWgSum2 + (c & 3) * 64 + 16 * g + (c >> 2);
+            dst = p.db2 + (size_t)b * 64 + c;
+        } else {
+            const int o = f - 128;
+            for (int g = 0; g < 4; ++g) idx[g] = kWgSum3 + 16 * g + o;
+            dst = p.db3 + (size_t)b * 4 + o;
+        }
+    }
+    const float *part = p.partial + (size_t)b * p.chunks * kWgPartial;
+    float acc = 0.0f;
+    for (int ch = 0; ch < nch; ++ch)
+        for (int g = 0; g < nidx; ++g) acc += part[(size_t)ch * kWgPartial + idx[g]];
+    *dst = acc;
+}
+
 // ---- backward of ModulatedConv1d's weight path: dW' -> d conv.weight, d modulation.{weight,bias}, d z_rend ---------------
 // u = (W / sqrt(in)) * s (s broadcast over rows), W' = u / max(||u||_row, 1e-12), s = z Wm^T / sqrt(D) + bm
 __global__ __launch_bounds__(256) void prepare_bwd_kernel(const enarf_prepare_bwd_args a) {
@@ -456,6 +578,35 @@ extern "C" int enarf_triplane_unpack_add(const float *grad_feat_cl, float *grad_
     hipLaunchKernelGGL(unpack_add_kernel, dim3((W + 63) / 64, H, B * 3), dim3(256), 0, (hipStream_t)stream, grad_feat_cl,
                        grad_tri_nchw, channels_total, H, W);
     return host::check_launch("enarf_triplane_unpack_add");
+}
+
+extern "C" size_t enarf_weight_grad_workspace_bytes(int B, long long rows_per_image) {
+    if (B <= 0 || rows_per_image <= 0) return 0;
+    const long long chunks = (rows_per_image + kWgRowsPerWave - 1) / kWgRowsPerWave;
+    return (size_t)B * (size_t)chunks * kWgPartial * sizeof(float);
+}
+
+extern "C" int enarf_weight_grad(const enarf_weight_grad_args *args, enarf_stream_t stream) {
+    if (!args) return host::fail(ENARF_ERR_ARG, "enarf_weight_grad: args is null");
+    const enarf_weight_grad_args &a = *args;
+    if (a.B <= 0 || a.B > 65535 || a.rows_per_image <= 0 || a.rows_per_image % 16 != 0)
+        return host::fail(ENARF_ERR_ARG, "enarf_weight_grad: bad sizes (B=%d rows_per_image=%lld)", a.B, a.rows_per_image);
+    if (!a.rows_x || !a.rows_h1 || !a.rows_h2 || !a.rows_dz1 || !a.rows_dz2 || !a.rows_dz3 || !a.row_blocks || !a.workspace ||
+        !a.dW1 || !a.dW2 || !a.dW3 || !a.db1 || !a.db2 || !a.db3)
+        return host::fail(ENARF_ERR_ARG, "enarf_weight_grad: null pointer");
+    WeightGradParams p;
+    p.x = a.rows_x; p.h1 = a.rows_h1; p.h2 = a.rows_h2; p.dz1 = a.rows_dz1; p.dz2 = a.rows_dz2; p.dz3 = a.rows_dz3;
+    p.rows_per_image = a.rows_per_image; p.row_blocks = a.row_blocks;
+    p.partial = reinterpret_cast<float *>(a.workspace);
+    const long long chunks = (a.rows_per_image + kWgRowsPerWave - 1) / kWgRowsPerWave;
+    if (chunks > 0x3FFFFFFFll) return host::fail(ENARF_ERR_UNSUPPORTED, "enarf_weight_grad: too many rows");
+    p.chunks = (int)chunks;
+    p.dW1 = a.dW1; p.dW2 = a.dW2; p.dW3 = a.dW3; p.db1 = a.db1; p.db2 = a.db2; p.db3 = a.db3;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(weight_grad_partial_kernel, dim3((unsigned)((chunks + 3) / 4), a.B), dim3(256), 0, st, p);
+    if (int rc = host::check_launch("enarf_weight_grad(partial)")) return rc;
+    hipLaunchKernelGGL(weight_grad_reduce_kernel, dim3((64 * 64 + 64 * 32 + 4 * 64 + 132 + 255) / 256, a.B), dim3(256), 0, st, p);
+    return host::check_launch("enarf_weight_grad(reduce)");
 }
 
 extern "C" int enarf_prepare_bwd(const enarf_prepare_bwd_args *args, enarf_stream_t stream) {

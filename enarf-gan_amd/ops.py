@@ -367,7 +367,7 @@ def render_bwd(image_coord, inv_intrinsics, parts, canonical_pose, tri_nchw, fea
     """Backward of render_fwd w.r.t. the tri-plane and the per-image demodulated MLP weights / biases.
 
     Returns (grad_tri (same batch as tri_nchw: 1 for a shared tri-plane), dW [3 x (B,out,in)], db [3 x (out,)]).
-    The weight gradients are formed from the kernel's per-tile rows with a library GEMM (torch.matmul = rocBLAS)."""
+    The weight gradients are formed from the kernel's per-tile rows by enarf_weight_grad (MFMA split-K, no host sync)."""
     lib = _lib.load()
     coord = _dev_f32(image_coord, "image_coord")
     B, n = coord.shape[0], coord.shape[-1]
@@ -410,19 +410,19 @@ def render_bwd(image_coord, inv_intrinsics, parts, canonical_pose, tri_nchw, fea
     _lib.check(lib.enarf_render_bwd(C.byref(a), _stream(dev)), "enarf_render_bwd")
     _lib.check(lib.enarf_triplane_unpack_add(_p(gfeat), _p(grad_tri), grad_tri.shape[0], Ct, H, W, _stream(dev)),
                "enarf_triplane_unpack_add")
-    # weight gradients per image: dW'_l = dZ_l^T H_{l-1}  (library GEMM over the rows the kernel wrote)
-    counts = (blocks.cpu().to(torch.int64) * 16).tolist()
-    dW = [torch.zeros(B, 64, 32, device=dev), torch.zeros(B, 64, 64, device=dev), torch.zeros(B, 4, 64, device=dev)]
-    db = [torch.zeros(64, device=dev), torch.zeros(64, device=dev), torch.zeros(4, device=dev)]
-    for b in range(B):
-        r = counts[b]
-        if r == 0:
-            continue
-        ins = (bufs["x"][b, :r], bufs["h1"][b, :r], bufs["h2"][b, :r])
-        dzs = (bufs["dz1"][b, :r], bufs["dz2"][b, :r], bufs["dz3"][b, :r])
-        for l in range(3):
-            dW[l][b] = dzs[l].t() @ ins[l]
-            db[l] += dzs[l].sum(dim=0)
+    # weight gradients per image: dW'_l = dZ_l^T H_{l-1}, db_l = column sums of dZ_l, from the rows the kernel wrote
+    dW = [torch.empty(B, 64, 32, device=dev), torch.empty(B, 64, 64, device=dev), torch.empty(B, 4, 64, device=dev)]
+    dbb = [torch.empty(B, 64, device=dev), torch.empty(B, 64, device=dev), torch.empty(B, 4, device=dev)]
+    w = _lib.WeightGradArgs()
+    w.B, w.rows_per_image, w.row_blocks = B, rows, _p(blocks)
+    w.rows_x, w.rows_h1, w.rows_h2 = _p(bufs["x"]), _p(bufs["h1"]), _p(bufs["h2"])
+    w.rows_dz1, w.rows_dz2, w.rows_dz3 = _p(bufs["dz1"]), _p(bufs["dz2"]), _p(bufs["dz3"])
+    w.dW1, w.dW2, w.dW3 = _p(dW[0]), _p(dW[1]), _p(dW[2])
+    w.db1, w.db2, w.db3 = _p(dbb[0]), _p(dbb[1]), _p(dbb[2])
+    wws = torch.empty(int(lib.enarf_weight_grad_workspace_bytes(B, rows)) // 4, dtype=torch.float32, device=dev)
+    w.workspace = _p(wws)
+    _lib.check(lib.enarf_weight_grad(C.byref(w), _stream(dev)), "enarf_weight_grad")
+    db = [t.sum(dim=0) for t in dbb]
     return grad_tri, dW, db
 
 

@@ -255,6 +255,22 @@ typedef struct {
 long long enarf_render_bwd_rows_per_image(int n, int Nf);
 int enarf_render_bwd(const enarf_render_bwd_args *args, enarf_stream_t stream);
 
+/* Weight gradients of the per-image (demodulated) StyledMLP from the rows enarf_render_bwd exported:
+ *   dW1 (B,64,32) = dZ1^T X, dW2 (B,64,64) = dZ2^T H1, dW3 (B,4,64) = dZ3^T H2, db_l (B, out) = column sums of dZ_l,
+ * over the first 16 * row_blocks[b] rows of image b. Replaces autograd through conv1d(groups=B)
+ * (libraries/custom_stylegan2/net.py:240-243) for the rendered samples. Deterministic (no atomics).
+ * workspace: enarf_weight_grad_workspace_bytes(B, rows_per_image) bytes of device memory. */
+typedef struct {
+    int B;
+    const float *rows_x, *rows_h1, *rows_h2, *rows_dz1, *rows_dz2, *rows_dz3;   /* as enarf_render_bwd_args */
+    long long rows_per_image;
+    const unsigned int *row_blocks;
+    float *dW1, *dW2, *dW3, *db1, *db2, *db3;
+    void *workspace;
+} enarf_weight_grad_args;
+size_t enarf_weight_grad_workspace_bytes(int B, long long rows_per_image);
+int enarf_weight_grad(const enarf_weight_grad_args *args, enarf_stream_t stream);
+
 typedef struct {
     int B, style_dim;
     const float *z_rend;                  /* (B, style_dim) */
