@@ -15,6 +15,10 @@
 #include "enarf_host.h"
 #include <cstdlib>
 
+#ifndef ENARF_BWD_ABLATE
+#define ENARF_BWD_ABLATE 0      // diagnosis builds only: 1 no feature atomics, 2 no mask atomics, 4 no scatter pass, 8 no row export
+#endif
+
 namespace enarf {
 
 constexpr int kBwdWavesPerSimd = 2;
@@ -52,12 +56,26 @@ __device__ __forceinline__ void scatter_tap(float *__restrict__ gpl, float *tile
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // each half-wave walks 8 consecutive quads (= consecutive samples along the ray, which mostly fall on the same
+    // texels: the importance samples cluster at the surface) and merges runs that target the same texel into ONE atomic
+    {
+        const int ch = lane & 31, h8 = (lane >> 5) * 8;
+        int run_o = -1;
+        float run_v = 0.0f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int tq = 2 * i + (lane >> 5), ch = lane & 31;
-        const int o = toff[tq];
-        const float v = tile[tq * kTRow + ch];
-        if (o >= 0) atomicAdd(gpl + (size_t)o * kFeat + ch, v);
+        for (int i = 0; i < 8; ++i) {
+            const int tq = h8 + i;
+            const int o = toff[tq];
+            const float v = tile[tq * kTRow + ch];
+            if (o == run_o) {
+                run_v += v;
+            } else {
+                if (run_o >= 0 && !(ENARF_BWD_ABLATE & 1)) atomicAdd(gpl + (size_t)run_o * kFeat + ch, run_v);
+                run_o = o;
+                run_v = v;
+            }
+        }
+        if (run_o >= 0 && !(ENARF_BWD_ABLATE & 1)) atomicAdd(gpl + (size_t)run_o * kFeat + ch, run_v);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -120,7 +138,8 @@ __global__ __launch_bounds__(256, kBwdWavesPerSimd) void render_bwd_kernel(const
             }
             S.feat = a.feat_cl + (size_t)b * a.feat_batch_stride;
             S.mask = a.mask_planes + (size_t)b * a.mask_batch_stride;
-            gfeat = a.grad_feat_cl + (size_t)b * a.grad_feat_batch_stride;
+            gfeat = a.grad_feat_cl + (size_t)b * a.grad_feat_batch_stride +
+                    (size_t)(xcc_id() % a.grad_feat_copies) * a.grad_feat_copy_stride;
             gmask = a.grad_mask_planes + (size_t)b * a.grad_mask_batch_stride;
             __syncthreads();
         }
@@ -155,7 +174,7 @@ __global__ __launch_bounds__(256, kBwdWavesPerSimd) void render_bwd_kernel(const
             bits |= (uint32_t)quad_perm_i<0x4E>((int)bits);
 #pragma unroll
             for (int c = 0; c < 8; ++c) feat[c] = 0.0f;
-            uint32_t rem = bits;
+            uint32_t rem = (ENARF_BWD_ABLATE & 4) ? 0u : bits;
             while (true) {
                 const uint64_t bal = __ballot(rem != 0);
                 if (bal == 0) break;
@@ -260,7 +279,7 @@ __global__ __launch_bounds__(256, kBwdWavesPerSimd) void render_bwd_kernel(const
             if (lane == 0) blk = atomicAdd(a.row_blocks + b, 1u);
             blk = (unsigned int)__builtin_amdgcn_readfirstlane((int)blk);
             const size_t row = (size_t)b * a.rows_per_image + (size_t)blk * 16 + mj;
-            {
+            if (!(ENARF_BWD_ABLATE & 8)) {
                 f32x4 *rx = reinterpret_cast<f32x4 *>(a.rows_x + row * 32 + 8 * mg);
                 rx[0] = f32x4{x[0], x[1], x[2], x[3]};
                 rx[1] = f32x4{x[4], x[5], x[6], x[7]};
@@ -280,7 +299,7 @@ __global__ __launch_bounds__(256, kBwdWavesPerSimd) void render_bwd_kernel(const
             for (int c = 0; c < 8; ++c) dxg[c] = __shfl(dxm[c], src2);
 
             // ---- F4: second pass over the pairs: d part-probability and d feature texels
-            uint32_t rem = bits;
+            uint32_t rem = (ENARF_BWD_ABLATE & 4) ? 0u : bits;
             while (true) {
                 const uint64_t bal = __ballot(rem != 0);
                 if (bal == 0) break;
@@ -317,7 +336,7 @@ __global__ __launch_bounds__(256, kBwdWavesPerSimd) void render_bwd_kernel(const
                 }
                 dot += quad_perm_f<0xB1>(dot);
                 dot += quad_perm_f<0x4E>(dot);                                  // d loss / d w_k, quad-uniform
-                if (act && g4 < 3) {   // w = s0 s1 s2, s = sigmoid(m): dw/dm_g = w (1 - s_g)
+                if (act && g4 < 3 && !(ENARF_BWD_ABLATE & 2)) {   // w = s0 s1 s2, s = sigmoid(m): dw/dm_g = w (1 - s_g)
                     const float gm = dot * wk * (1.0f - sg);
                     float *gp = gmask + (size_t)(3 * k + g4) * mplane;
                     if (t.w00 != 0.0f) atomicAdd(gp + t.o00, t.w00 * gm);
@@ -359,9 +378,9 @@ __global__ __launch_bounds__(256) void unpack_add_kernel(const float *__restrict
 // outputs and spends 0.8 ms on each; here every WAVE streams its own chunk of rows through v_mfma_f32_16x16x4_f32
 // (4 rows per step, operands straight from coalesced 16-B loads: lane l reads row l/16, columns 4(l%16)..+3, and
 // register r of that load is the operand block "columns 4i + r" - a permutation of the output that the second kernel
-// undoes), keeps all three products in 112 accumulator registers, and stores its partial; a second kernel sums the
-// partials. No atomics: the result is deterministic.
-constexpr int kWgRowsPerWave = 1024;
+// undoes) and keeps all three products in 112 accumulator registers; the four waves of a workgroup add their partials
+// up in LDS and store one partial per 1024 rows; a second kernel sums the partials. No atomics: deterministic.
+constexpr int kWgRowsPerWave = 256, kWgRowsPerWg = 4 * kWgRowsPerWave;
 constexpr int kWgAcc2 = 0, kWgAcc1 = 16 * 256, kWgAcc3 = kWgAcc1 + 8 * 256, kWgSum2 = kWgAcc3 + 4 * 256;
 constexpr int kWgSum1 = kWgSum2 + 256, kWgSum3 = kWgSum1 + 256, kWgPartial = kWgSum3 + 64;      // floats per wave chunk
 
@@ -370,17 +389,18 @@ struct WeightGradParams {
     long long rows_per_image;
     const unsigned int *row_blocks;
     float *partial;            // [B][chunks][kWgPartial]
-    int chunks;                // wave chunks per image the launch covers
+    int chunks;                // workgroup chunks (kWgRowsPerWg rows) per image the launch covers
     float *dW1, *dW2, *dW3, *db1, *db2, *db3;
 };
 
 __global__ __launch_bounds__(256) void weight_grad_partial_kernel(const WeightGradParams p) {
+    __shared__ float red[kWgPartial];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.y;
-    const int chunk = blockIdx.x * 4 + wave;
+    const int chunk = blockIdx.x;
     const long long count = (long long)p.row_blocks[b] * 16;
-    const long long r0 = (long long)chunk * kWgRowsPerWave;
-    if (chunk >= p.chunks || r0 >= count) return;             // wave-uniform
-    const long long r1 = (r0 + kWgRowsPerWave < count) ? r0 + kWgRowsPerWave : count;   // multiple of 16
+    if ((long long)chunk * kWgRowsPerWg >= count) return;      // block-uniform
+    const long long r0 = (long long)chunk * kWgRowsPerWg + (long long)wave * kWgRowsPerWave;
+    const long long r1 = (r0 + kWgRowsPerWave < count) ? r0 + kWgRowsPerWave : count;   // multiple of 16; may be <= r0
     const int kg = lane >> 4, i16 = lane & 15;
     const size_t base = (size_t)b * p.rows_per_image;
     f32x4 acc2[16], acc1[8], acc3[4];
@@ -413,34 +433,45 @@ __global__ __launch_bounds__(256) void weight_grad_partial_kernel(const WeightGr
         for (int c = 0; c < 4; ++c) { s2[c] += vdz2[c]; s1[c] += vdz1[c]; }
         s3 += vdz3;
     }
+    // the four waves add up in LDS, one after the other (a wave with no rows adds zeros), then store once
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+            auto put = [&](int idx, float v) { red[idx] = (w == 0) ? v : red[idx] + v; };
+#pragma unroll
+            for (int t = 0; t < 16; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) put(kWgAcc2 + (t * 4 + q) * 64 + lane, acc2[t][q]);
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) put(kWgAcc1 + (t * 4 + q) * 64 + lane, acc1[t][q]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) put(kWgAcc3 + (t * 4 + q) * 64 + lane, acc3[t][q]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { put(kWgSum2 + c * 64 + lane, s2[c]); put(kWgSum1 + c * 64 + lane, s1[c]); }
+            put(kWgSum3 + lane, s3);
+        }
+        __syncthreads();
+    }
     float *out = p.partial + ((size_t)b * p.chunks + chunk) * kWgPartial;
-#pragma unroll
-    for (int t = 0; t < 16; ++t)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) out[kWgAcc2 + (t * 4 + q) * 64 + lane] = acc2[t][q];
-#pragma unroll
-    for (int t = 0; t < 8; ++t)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) out[kWgAcc1 + (t * 4 + q) * 64 + lane] = acc1[t][q];
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) out[kWgAcc3 + (t * 4 + q) * 64 + lane] = acc3[t][q];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) { out[kWgSum2 + c * 64 + lane] = s2[c]; out[kWgSum1 + c * 64 + lane] = s1[c]; }
-    out[kWgSum3 + lane] = s3;
+    for (int i = threadIdx.x; i < kWgPartial; i += 256) out[i] = red[i];
 }
 
-// one thread per output element: sums the wave partials that hold it (and undoes the operand permutation)
+// four threads per output element (64 elements per block): each sums every fourth partial that holds the element (and
+// undoes the operand permutation), then the four add up through LDS
 __global__ __launch_bounds__(256) void weight_grad_reduce_kernel(const WeightGradParams p) {
-    const int e = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    __shared__ float red[256];
+    const int el = threadIdx.x & 63, part4 = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + el, b = blockIdx.y;
     constexpr int N2 = 64 * 64, N1 = 64 * 32, N3 = 4 * 64, NB = 64 + 64 + 4;
-    if (e >= N2 + N1 + N3 + NB) return;
+    const bool in_range = e < N2 + N1 + N3 + NB;
     const long long count = (long long)p.row_blocks[b] * 16;
-    const int valid = (int)((count + kWgRowsPerWave - 1) / kWgRowsPerWave);
+    const int valid = (int)((count + kWgRowsPerWg - 1) / kWgRowsPerWg);
     const int nch = valid < p.chunks ? valid : p.chunks;
-    int idx[4], nidx = 1;
-    float *dst;
+    int idx[4] = {0, 0, 0, 0}, nidx = 1;
+    float *dst = nullptr;
     if (e < N2) {                       // dW2[m][c]: tile (m%4, c%4), register (m/4)%4, lane 16 (m/16) + c/4
         const int m = e / 64, c = e % 64;
         idx[0] = kWgAcc2 + (((m & 3) * 4 + (c & 3)) * 4 + ((m >> 2) & 3)) * 64 + 16 * (m >> 4) + (c >> 2);
@@ -453,7 +484,7 @@ __global__ __launch_bounds__(256) void weight_grad_reduce_kernel(const WeightGra
         const int f = e - N2 - N1, o = f / 64, c = f % 64;
         idx[0] = kWgAcc3 + ((c & 3) * 4 + o) * 64 + (c >> 2);
         dst = p.dW3 + (size_t)b * N3 + f;
-    } else {                            // biases: column sums held by the four k-groups of lanes
+    } else if (in_range) {              // biases: column sums held by the four k-groups of lanes
         const int f = e - N2 - N1 - N3;
         nidx = 4;
         if (f < 64) {
@@ -471,9 +502,12 @@ __global__ __launch_bounds__(256) void weight_grad_reduce_kernel(const WeightGra
     }
     const float *part = p.partial + (size_t)b * p.chunks * kWgPartial;
     float acc = 0.0f;
-    for (int ch = 0; ch < nch; ++ch)
-        for (int g = 0; g < nidx; ++g) acc += part[(size_t)ch * kWgPartial + idx[g]];
-    *dst = acc;
+    if (in_range)
+        for (int ch = part4; ch < nch; ch += 4)
+            for (int g = 0; g < nidx; ++g) acc += part[(size_t)ch * kWgPartial + idx[g]];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (in_range && part4 == 0) *dst = ((red[el] + red[64 + el]) + red[128 + el]) + red[192 + el];
 }
 
 // ---- backward of ModulatedConv1d's weight path: dW' -> d conv.weight, d modulation.{weight,bias}, d z_rend ---------------
@@ -544,6 +578,7 @@ extern "C" int enarf_render_bwd(const enarf_render_bwd_args *args, enarf_stream_
     const enarf_render_bwd_args &a = *args;
     if (a.B <= 0 || a.n <= 0 || a.P <= 0 || a.P > ENARF_MAX_PARTS || a.H <= 0 || a.W <= 0)
         return host::fail(ENARF_ERR_ARG, "enarf_render_bwd: bad sizes");
+    if (a.grad_feat_copies != 1 && a.grad_feat_copies != 8) return host::fail(ENARF_ERR_ARG, "enarf_render_bwd: grad_feat_copies must be 1 or 8");
     if (a.Nf < 2 || a.Nf > 64) return host::fail(ENARF_ERR_UNSUPPORTED, "enarf_render_bwd: Nf=%d outside [2, 64]", a.Nf);
     if (!a.image_coord || !a.inv_intrinsics || !a.parts || !a.canonical_pose || !a.feat_cl || !a.mask_planes || !a.mlp_pack ||
         !a.bins || !a.grad_feat_cl || !a.grad_mask_planes || !a.rows_x || !a.rows_h1 || !a.rows_h2 || !a.rows_dz1 ||
@@ -582,7 +617,7 @@ extern "C" int enarf_triplane_unpack_add(const float *grad_feat_cl, float *grad_
 
 extern "C" size_t enarf_weight_grad_workspace_bytes(int B, long long rows_per_image) {
     if (B <= 0 || rows_per_image <= 0) return 0;
-    const long long chunks = (rows_per_image + kWgRowsPerWave - 1) / kWgRowsPerWave;
+    const long long chunks = (rows_per_image + kWgRowsPerWg - 1) / kWgRowsPerWg;
     return (size_t)B * (size_t)chunks * kWgPartial * sizeof(float);
 }
 
@@ -598,14 +633,14 @@ extern "C" int enarf_weight_grad(const enarf_weight_grad_args *args, enarf_strea
     p.x = a.rows_x; p.h1 = a.rows_h1; p.h2 = a.rows_h2; p.dz1 = a.rows_dz1; p.dz2 = a.rows_dz2; p.dz3 = a.rows_dz3;
     p.rows_per_image = a.rows_per_image; p.row_blocks = a.row_blocks;
     p.partial = reinterpret_cast<float *>(a.workspace);
-    const long long chunks = (a.rows_per_image + kWgRowsPerWave - 1) / kWgRowsPerWave;
+    const long long chunks = (a.rows_per_image + kWgRowsPerWg - 1) / kWgRowsPerWg;
     if (chunks > 0x3FFFFFFFll) return host::fail(ENARF_ERR_UNSUPPORTED, "enarf_weight_grad: too many rows");
     p.chunks = (int)chunks;
     p.dW1 = a.dW1; p.dW2 = a.dW2; p.dW3 = a.dW3; p.db1 = a.db1; p.db2 = a.db2; p.db3 = a.db3;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(weight_grad_partial_kernel, dim3((unsigned)((chunks + 3) / 4), a.B), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(weight_grad_partial_kernel, dim3((unsigned)chunks, a.B), dim3(256), 0, st, p);
     if (int rc = host::check_launch("enarf_weight_grad(partial)")) return rc;
-    hipLaunchKernelGGL(weight_grad_reduce_kernel, dim3((64 * 64 + 64 * 32 + 4 * 64 + 132 + 255) / 256, a.B), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(weight_grad_reduce_kernel, dim3((64 * 64 + 64 * 32 + 4 * 64 + 132 + 63) / 64, a.B), dim3(256), 0, st, p);
     return host::check_launch("enarf_weight_grad(reduce)");
 }
 
