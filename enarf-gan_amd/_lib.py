@@ -73,7 +73,6 @@ class RenderBwdArgs(C.Structure):
         ("mlp_pack", _f32p), ("bins", _f32p),
         ("g_color", _f32p), ("g_mask", _f32p), ("g_disparity", _f32p),
         ("grad_feat_cl", _f32p), ("grad_feat_batch_stride", C.c_longlong),
-        ("grad_feat_copies", C.c_int), ("grad_feat_copy_stride", C.c_longlong),
         ("grad_mask_planes", _f32p), ("grad_mask_batch_stride", C.c_longlong),
         ("rows_x", _f32p), ("rows_h1", _f32p), ("rows_h2", _f32p), ("rows_dz1", _f32p), ("rows_dz2", _f32p),
         ("rows_dz3", _f32p), ("rows_per_image", C.c_longlong), ("row_blocks", _f32p), ("workspace", _f32p),

@@ -138,8 +138,7 @@ __global__ __launch_bounds__(256, kBwdWavesPerSimd) void render_bwd_kernel(const
             }
             S.feat = a.feat_cl + (size_t)b * a.feat_batch_stride;
             S.mask = a.mask_planes + (size_t)b * a.mask_batch_stride;
-            gfeat = a.grad_feat_cl + (size_t)b * a.grad_feat_batch_stride +
-                    (size_t)(xcc_id() % a.grad_feat_copies) * a.grad_feat_copy_stride;
+            gfeat = a.grad_feat_cl + (size_t)b * a.grad_feat_batch_stride;
             gmask = a.grad_mask_planes + (size_t)b * a.grad_mask_batch_stride;
             __syncthreads();
         }
@@ -578,7 +577,6 @@ extern "C" int enarf_render_bwd(const enarf_render_bwd_args *args, enarf_stream_
     const enarf_render_bwd_args &a = *args;
     if (a.B <= 0 || a.n <= 0 || a.P <= 0 || a.P > ENARF_MAX_PARTS || a.H <= 0 || a.W <= 0)
         return host::fail(ENARF_ERR_ARG, "enarf_render_bwd: bad sizes");
-    if (a.grad_feat_copies != 1 && a.grad_feat_copies != 8) return host::fail(ENARF_ERR_ARG, "enarf_render_bwd: grad_feat_copies must be 1 or 8");
     if (a.Nf < 2 || a.Nf > 64) return host::fail(ENARF_ERR_UNSUPPORTED, "enarf_render_bwd: Nf=%d outside [2, 64]", a.Nf);
     if (!a.image_coord || !a.inv_intrinsics || !a.parts || !a.canonical_pose || !a.feat_cl || !a.mask_planes || !a.mlp_pack ||
         !a.bins || !a.grad_feat_cl || !a.grad_mask_planes || !a.rows_x || !a.rows_h1 || !a.rows_h2 || !a.rows_dz1 ||

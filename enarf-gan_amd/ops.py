@@ -385,10 +385,7 @@ def render_bwd(image_coord, inv_intrinsics, parts, canonical_pose, tri_nchw, fea
             for k, w in (("x", 32), ("h1", 64), ("h2", 64), ("dz1", 64), ("dz2", 64), ("dz3", 4))}
     blocks = torch.zeros(B, dtype=torch.int32, device=dev)
     grad_tri = torch.zeros_like(tri)
-    # one private gradient copy per XCD while that stays under 2 GiB (atomics from different XCDs on the same line bounce
-    # it between their L2s); summed before the inverse re-layout
-    copies = 8 if feat_cl.numel() * 4 * 8 <= (2 << 30) else 1
-    gfeat = torch.zeros((copies,) + tuple(feat_cl.shape), dtype=torch.float32, device=dev)
+    gfeat = torch.zeros_like(feat_cl)
     a = _lib.RenderBwdArgs()
     a.B, a.n, a.P, a.Nf, a.H, a.W = B, n, P, Nf, H, W
     a.drop_invalid_rays = int(B == 1 if drop_invalid_rays is None else drop_invalid_rays)
@@ -405,15 +402,13 @@ def render_bwd(image_coord, inv_intrinsics, parts, canonical_pose, tri_nchw, fea
     gd = None if g_disparity is None else _dev_f32(g_disparity, "g_disparity").reshape(B, n)
     a.g_color, a.g_mask, a.g_disparity = _p(gc), _p(gm), _p(gd)
     a.grad_feat_cl, a.grad_feat_batch_stride = _p(gfeat), fstride
-    a.grad_feat_copies, a.grad_feat_copy_stride = copies, feat_cl.numel()
     a.grad_mask_planes, a.grad_mask_batch_stride = grad_tri.data_ptr() + PLANE_CH * H * W * 4, mstride
     a.rows_x, a.rows_h1, a.rows_h2 = _p(bufs["x"]), _p(bufs["h1"]), _p(bufs["h2"])
     a.rows_dz1, a.rows_dz2, a.rows_dz3 = _p(bufs["dz1"]), _p(bufs["dz2"]), _p(bufs["dz3"])
     a.rows_per_image, a.row_blocks = rows, _p(blocks)
     a.workspace = _p(_render_workspace(dev, B, n))
     _lib.check(lib.enarf_render_bwd(C.byref(a), _stream(dev)), "enarf_render_bwd")
-    gsum = gfeat[0] if copies == 1 else gfeat.sum(dim=0)
-    _lib.check(lib.enarf_triplane_unpack_add(_p(gsum), _p(grad_tri), grad_tri.shape[0], Ct, H, W, _stream(dev)),
+    _lib.check(lib.enarf_triplane_unpack_add(_p(gfeat), _p(grad_tri), grad_tri.shape[0], Ct, H, W, _stream(dev)),
                "enarf_triplane_unpack_add")
     # weight gradients per image: dW'_l = dZ_l^T H_{l-1}, db_l = column sums of dZ_l, from the rows the kernel wrote
     dW = [torch.empty(B, 64, 32, device=dev), torch.empty(B, 64, 64, device=dev), torch.empty(B, 4, 64, device=dev)]

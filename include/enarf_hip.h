@@ -244,9 +244,7 @@ typedef struct {
     const void *mlp_pack;
     const float *bins;                    /* device (B, n, Nf): the bins the forward used (its dbg_bins output) */
     const float *g_color, *g_mask, *g_disparity;   /* upstream gradients (B,3,n), (B,n), (B,n); NULL = zero */
-    float *grad_feat_cl; long long grad_feat_batch_stride;      /* (copies, B|1, 3, H, W, 32), zero-filled by the caller */
-    int grad_feat_copies; long long grad_feat_copy_stride;      /* 1, or 8: one private copy per XCD (the caller sums them) -
-                                                                   atomics from different XCDs on one line bounce it between L2s */
+    float *grad_feat_cl; long long grad_feat_batch_stride;      /* (B|1, 3, H, W, 32), zero-filled by the caller */
     float *grad_mask_planes; long long grad_mask_batch_stride;  /* &grad_tri[0][96][0][0], zero-filled by the caller */
     float *rows_x, *rows_h1, *rows_h2, *rows_dz1, *rows_dz2, *rows_dz3;   /* (B, rows_per_image, 32|64|64|64|64|4) */
     long long rows_per_image;             /* >= enarf_render_bwd_rows_per_image(n, Nf) */
