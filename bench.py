@@ -46,6 +46,11 @@ def parse():
                     help="re-lay the (constant) tri-plane once instead of every step")
     ap.add_argument("--distinct-triplanes", action="store_true",
                     help="GAN style: one tri-plane per frame (generated on the device) instead of one shared constant tri-plane")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="HIP streams the steps alternate over, each with its own intermediates (part frames, MLP packs, "
+                         "channel-last planes, workspace). With 2, the pre-march launch of step i+1 fills the CUs that the "
+                         "persistent march of step i frees in its tail (+7 %% rays/s), but event-bracketed kernel times then "
+                         "include the overlap, so the default - and the roofline figure - is strictly serial steps")
     ap.add_argument("--unfused", action="store_true",
                     help="issue prepare / re-layout / render as the three separate C-ABI calls (4 launches + memset) "
                          "instead of enarf_render_step_fwd (2 launches + memset)")
@@ -119,15 +124,21 @@ def main():
     mlp = {k: v.to(dev) for k, v in sc["mlp"].items()}
     cpose_d, cbl_d = cpose.to(dev), cbl.to(dev)
     coord = d["image_coord"].reshape(B, 3, n).contiguous()
-    feat_cl = torch.empty(tri.shape[0], 3, 256, 256, 32, device=dev)
-    parts = torch.empty(B, P, 16, device=dev)
-    pack = torch.empty(B, ops.mlp_pack_bytes(), dtype=torch.uint8, device=dev)
-    ops.triplane_pack(tri, feat_cl)
+    n_streams = 1 if args.unfused else max(1, args.streams)
+    streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(n_streams - 1)]
+    sets = []                                      # per-stream intermediates: steps on different streams share only inputs
+    for _ in range(n_streams):
+        f = torch.empty(tri.shape[0], 3, 256, 256, 32, device=dev)
+        ops.triplane_pack(tri, f)
+        sets.append((f, torch.empty(B, P, 16, device=dev), torch.empty(B, ops.mlp_pack_bytes(), dtype=torch.uint8, device=dev)))
+    feat_cl, parts, pack = sets[0]
+    torch.cuda.synchronize()
 
-    def bound_step(seed, count=False):
+    def bound_step(seed, count=False, k=0):
+        f, pa, pk = sets[k]
         return ops.RenderStep(d["pose_to_camera"], d["bone_length"], cbl_d, d["z_rend"], mlp, sc["parents"], args.origin,
-                              3.0, coord, d["inv_intrinsics"], cpose_d, tri, feat_cl, Nc, Nf, parts_out=parts,
-                              pack_out=pack, relayout=not args.cache_triplane, seed=seed, mlp_mode=args.mlp_mode,
+                              3.0, coord, d["inv_intrinsics"], cpose_d, tri, f, Nc, Nf, parts_out=pa,
+                              pack_out=pk, relayout=not args.cache_triplane, seed=seed, mlp_mode=args.mlp_mode,
                               want_fine=True, count=count, early_stop_eps=args.early_stop_eps)
 
     def step(i, count=False):
@@ -147,7 +158,11 @@ def main():
     V, tiles, rays_marched, rounds = [int(x) for x in cnt[:4].tolist()]
 
     for i in range(args.warmup):
-        step(i)
+        with torch.cuda.stream(streams[i % n_streams]):
+            if args.unfused:
+                step(i)
+            else:
+                bound_step(99 + i, k=i % n_streams).run()
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     torch.cuda.synchronize()
@@ -156,11 +171,13 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         if not args.unfused:      # same two launches as enarf_render_step_fwd(ENARF_STEP_ALL), with the march bracketed
-            st = bound_step(99)
-            st.run(ops.STEP_PRE)
-            ev0[i].record()
-            st.run(ops.STEP_MARCH)
-            ev1[i].record()
+            k = i % n_streams
+            with torch.cuda.stream(streams[k]):
+                st = bound_step(99, k=k)
+                st.run(ops.STEP_PRE)
+                ev0[i].record()
+                st.run(ops.STEP_MARCH)
+                ev1[i].record()
             continue
         ops.prepare(d["pose_to_camera"], d["bone_length"], cbl_d, d["z_rend"], mlp, sc["parents"], args.origin,
                     3.0, parts_out=parts, pack_out=pack)
@@ -201,7 +218,7 @@ def main():
             "config": {"workload": f"C1: DSO-style {S}x{S} frame, Nc {Nc} + Nf {Nf} samples/ray, 24 joints -> P={P} parts "
                                    f"({args.origin}), {B} frame/GPU/step, {'per-frame' if tri.shape[0] > 1 else 'constant'} fp32 tri-plane 256^2x(96+{3 * P}), "
                                    f"in-kernel Philox importance sampling",
-                       "mlp_arith": args.mlp_mode, "early_stop_eps": args.early_stop_eps, "triplane_relayout_in_step": not args.cache_triplane,
+                       "streams": n_streams, "mlp_arith": args.mlp_mode, "early_stop_eps": args.early_stop_eps, "triplane_relayout_in_step": not args.cache_triplane,
                        "step": ("enarf_prepare + enarf_triplane_pack + enarf_render_fwd" if args.unfused else
                                 "enarf_render_step_fwd (pre-march launch: re-layout + prepare + ray set-up; then the march)")},
             "roofline": {"bound": "hbm", "kernel": "enarf::render_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
