@@ -10,7 +10,7 @@ namespace enarf {
 // LDS staging shared by the query and render kernels
 // =================================================================================================
 // dynamic LDS layout (floats): [mlp section][bias 144][parts P*20][canon P*12][scratch kScratchFloats]
-constexpr int kScratchFloats = 1536;
+constexpr int kScratchFloats = 1664;
 template <int MODE>
 __host__ __device__ constexpr int lds_mlp_floats() {
     return (MODE == ENARF_MLP_F32) ? PK_B1 : PKH_SHORTS / 2;

@@ -506,7 +506,8 @@ constexpr int SC_FH = 648;        // fine: head [4][128]
 constexpr int SC_FBITS = 1160;    // fine: bits [128]
 constexpr int SC_FWMAX = 1288;    // fine: wmax [128]
 constexpr int SC_QUEUE = 1416;    // 2 ray ids (current / prefetched)
-static_assert(SC_QUEUE + kQueueLdsInts <= kScratchFloats, "scratch overflow");
+constexpr int SC_BINS = 1480;     // importance samples of the ray [128] + 8 skip flags (written by the one wave that runs S2)
+static_assert(SC_QUEUE + kQueueLdsInts <= SC_BINS && SC_BINS + kMaxSamples + 8 <= kScratchFloats, "scratch overflow");
 
 // SPL = samples per lane in the lane = sample stages: 1 for Nc, Nf <= 64, 2 up to 128 (each wave then loops over two
 // 16-sample tiles per pass)
@@ -624,10 +625,15 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
         const int next_ray = rq.get(qslot ^ 1);
         qslot ^= 1;
 
-        // ---- S2 (every wave, element e = 64 s + lane): weights (rendering.py:180-184), smoothing (:187-190), bins (:192-197)
-        float bin[SPL];
-        bool skip_tile[SPL];
-        {
+        // ---- S2 (ONE wave, element e = 64 s + lane): weights (rendering.py:180-184), smoothing (:187-190), bins (:192-197).
+        // The result goes through LDS; the other waves wait at the barrier instead of spending the same ~350 VALU
+        // instructions each (the SIMDs are shared with two other workgroups that can use the slots).
+        float *l_bins = scratch + SC_BINS;
+        int *l_skip = reinterpret_cast<int *>(scratch + SC_BINS + kMaxSamples);
+        if (wave == spare_wave) {
+            float bin[SPL];
+            bool skip_tile[4 * SPL];
+
             float dd[SPL], cs[SPL], T[SPL], wgt[SPL], ws[SPL], wl[SPL], wr[SPL];
 #pragma unroll
             for (int s = 0; s < SPL; ++s) {
@@ -635,7 +641,7 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
                 const bool active = e < Nc;
                 const int ci = min(e, Nc - 1);
                 const float den = active ? density_head(l_ch[ci], l_cbits[ci], l_cwmax[ci], S.mult_w, P) : 0.0f;
-                if (a.dbg_coarse_density && active && wave == 0) a.dbg_coarse_density[((size_t)b * n + ray) * Nc + e] = den;
+                if (a.dbg_coarse_density && active) a.dbg_coarse_density[((size_t)b * n + ray) * Nc + e] = den;
                 const float b0 = l_btab[ci], b1 = l_btab[ci + 1];
                 const float delta = exact_lerp(dmin, dmax, b1) - exact_lerp(dmin, dmax, b0);
                 dd[s] = active ? den * delta * a.render_scale : 0.0f;
@@ -697,34 +703,41 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
                     bin[s] = (64 * s + lane < Nf) ? ((float)lo + frac) / (float)Nc : 3.0e38f;
                 }
             }
-            if (a.dbg_bins && wave == 0) {
 #pragma unroll
-                for (int s = 0; s < SPL; ++s)
-                    if (64 * s + lane < Nf) a.dbg_bins[((size_t)b * n + ray) * Nf + 64 * s + lane] = bin[s];
+            for (int s = 0; s < SPL; ++s) {
+                l_bins[64 * s + lane] = bin[s];
+                if (a.dbg_bins && 64 * s + lane < Nf) a.dbg_bins[((size_t)b * n + ray) * Nf + 64 * s + lane] = bin[s];
             }
             // early ray termination (opt-in, early_stop_eps > 0): transmittance in front of the first fine sample of
-            // each of this wave's tiles, read off the coarse pass (T before coarse bin j). Once it is below eps every
-            // sample of the tile weighs < eps: the tile's gathers and MLP are skipped (its densities count as 0).
+            // each tile, read off the coarse pass (T before coarse bin j). Once it is below eps every sample of the tile
+            // weighs < eps: the tile's gathers and MLP are skipped (its densities count as 0).
 #pragma unroll
-            for (int u = 0; u < SPL; ++u) {
-                skip_tile[u] = false;
+            for (int t = 0; t < 4 * SPL; ++t) {
+                skip_tile[t] = false;
                 if (a.early_stop_eps > 0.0f) {
-                    const float b_first = wv_get<SPL>(bin, min(wave * Tf + 16 * u, Nf - 1));
+                    const float b_first = wv_get<SPL>(bin, min((t / SPL) * Tf + 16 * (t % SPL), Nf - 1));
                     const int jbin = min(max((int)(b_first * (float)Nc), 0), Nc - 1);
-                    skip_tile[u] = wv_get<SPL>(T, jbin) < a.early_stop_eps;
+                    skip_tile[t] = wv_get<SPL>(T, jbin) < a.early_stop_eps;
                 }
+                if (lane == 0) l_skip[t] = skip_tile[t] ? 1 : 0;
             }
         }
-
         TMR(S, 6);
         TMR4(S, 2);
+        __syncthreads();
+        TMR(S, 5);
+        TMR4(S, 6);
+        bool skip_tile[SPL];
+#pragma unroll
+        for (int s = 0; s < SPL; ++s) skip_tile[s] = l_skip[wave * SPL + s] != 0;
+
         // ---- S3: fine pass, wave w owns samples [w Tf, (w+1) Tf); the last sample only closes the last interval
 #pragma unroll
         for (int u = 0; u < SPL; ++u) {
             if (16 * u >= Tf) break;
             const int jj = 16 * u + j4, i = wave * Tf + jj;
             const bool active = (jj < Tf) && (i < (dbgq ? Nf : Nf - 1)) && !skip_tile[u];
-            const float bi = wv_get<SPL>(bin, min(i, Nf - 1));
+            const float bi = l_bins[min(i, Nf - 1)];
             const float px = exact_lerp(sx, ex, bi), py = exact_lerp(sy, ey, bi), pz = exact_lerp(sz, ez, bi);
             f32x4 o;
             bool ran;
@@ -758,7 +771,7 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
                 const uint32_t bits = l_fbits[ci];
                 den[s] = have ? density_head(l_fh[3 * kMaxSamples + ci], bits, l_fwmax[ci], S.mult_w, P) : 0.0f;
                 cr[s] = tanhf(l_fh[ci]); cg[s] = tanhf(l_fh[kMaxSamples + ci]); cb[s] = tanhf(l_fh[2 * kMaxSamples + ci]);
-                fdepth[s] = exact_lerp(dmin, dmax, bin[s]);
+                fdepth[s] = exact_lerp(dmin, dmax, l_bins[64 * s + lane]);
                 if (dbgq && e < Nf) {
                     const size_t o = ((size_t)b * n + ray) * Nf + e;
                     a.dbg_fine_density[o] = den[s];
