@@ -424,3 +424,40 @@ def test_render_ragged_ray_count_batch3_every_ray_marched_once(ops):
     assert_close(_cpu(out.mask), rm, "mask")
     assert_close(_cpu(out.disparity), rd, "disparity")
     assert int(_cpu(out.counters)[2]) == 3 * 333
+
+
+def test_render_edge_cases_no_hit_single_ray_minimal_samples(ops):
+    """Degenerate launches: a frame whose rays all miss (batch 1: everything dropped, nothing marched), a single ray,
+    the smallest sample counts, and a batch in which one image has no hit at all - each against the oracle."""
+    sc = Scene(32, 1, "center_fixed", 20)
+    ds = DeviceScene(sc)
+    full = sc.raw["image_coord"]
+    # (a) rays pointing away from the body: flip the pixel coordinates far outside the frame
+    away = full.clone()
+    away[:, :, 0] += 1.0e4
+    out = ds.render(away[..., :200].contiguous(), 48, 32, None, seed=1, count=True, debug=True)
+    assert int(_cpu(out.counters)[2]) == 0 and int(_cpu(out.taps["ray_validity"]).sum()) == 0
+    for t in (out.color, out.mask, out.disparity, out.fine_weights, out.fine_depth):
+        assert float(t.abs().max()) == 0.0
+    # (b) one ray (a hit: centre of the frame), (c) minimal sample counts
+    mid = full[..., 16 * 32 + 16:16 * 32 + 17].contiguous()
+    for Nc, Nf in ((48, 32), (2, 2), (16, 3)):
+        g = torch.Generator().manual_seed(Nc)
+        bins = torch.rand(1, 1, Nf, generator=g).sort(-1).values
+        o1 = ds.render(mid, Nc, Nf, bins)
+        rc, rm, rd = sc.oracle_render(mid, Nc, Nf, bins, taps=False)
+        assert_close(_cpu(o1.color), rc, f"single ray colour Nc={Nc} Nf={Nf}")
+        assert_close(_cpu(o1.mask), rm, f"single ray mask Nc={Nc} Nf={Nf}")
+        assert_close(_cpu(o1.disparity), rd, f"single ray disparity Nc={Nc} Nf={Nf}")
+    # (d) batch of 2 where image 1 sees nothing: batch > 1 drops no ray, the empty image's rays are marched over [near, far]
+    sc2 = Scene(32, 2, "center_fixed", 20)
+    ds2 = DeviceScene(sc2)
+    coord = sc2.raw["image_coord"][..., 300:300 + 130].contiguous()
+    coord[1, :, 0] += 1.0e4
+    g = torch.Generator().manual_seed(7)
+    bins = torch.rand(2, 130, 32, generator=g).sort(-1).values
+    o2 = ds2.render(coord, 24, 32, bins, count=True)
+    rc, rm, rd = sc2.oracle_render(coord, 24, 32, bins, taps=False)
+    assert_close(_cpu(o2.color), rc, "half-empty batch colour")
+    assert_close(_cpu(o2.mask), rm, "half-empty batch mask")
+    assert int(_cpu(o2.counters)[2]) == 2 * 130 and float(_cpu(o2.mask)[1].abs().max()) == 0.0
