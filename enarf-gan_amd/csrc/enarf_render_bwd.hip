@@ -89,6 +89,165 @@ __device__ __forceinline__ void scatter_plane(float *__restrict__ gpl, float *ti
     scatter_tap(gpl, tile, t.o11, t.w11 * wk, on, dxg, lane);
 }
 
+
+// what the per-tile stages of the backward need besides the query context (shared by the ray and the point kernels)
+struct BwdTile {
+    int H, W;
+    size_t mplane, fplane;
+    const float *l_wt;                    // LDS: transposed weight section
+    float *rows_x, *rows_h1, *rows_h2, *rows_dz1, *rows_dz2, *rows_dz3;
+    long long rows_per_image;
+    unsigned int *row_blocks;
+    float *gfeat, *gmask;                 // this image's gradient planes
+    float *ttile;                         // this wave's atomic-transpose tile (LDS)
+};
+
+// F1, gather half: cube tests over the candidate parts, then the weighted features of the valid pairs (gather layout:
+// lane = 4 sample + chunk), exactly as the forward computes them
+__device__ __forceinline__ void bwd_gather_tile(const QueryCtx &S, const BwdTile &T, const int *l_cand, int ncand, float px,
+                                                float py, float pz, bool active, int lane, uint32_t &bits, float feat[8]) {
+    const int g4 = lane & 3;
+    {
+        uint32_t mine = 0;
+        for (int i0 = 0; i0 < ncand; i0 += 4) {
+            const int idx = i0 + g4;
+            const bool has = idx < ncand;
+            const int k = l_cand[has ? idx : 0];
+            float F[13], Cn[12], lx, ly, lz, cx, cy, cz;
+            load_frames(S, k, F, Cn);
+            exact_local(F, px, py, pz, lx, ly, lz);
+            exact_canonical(Cn, F[12], lx, ly, lz, cx, cy, cz);
+            if (active && has && in_unit_cube_incl(lx, ly, lz) && in_unit_cube_strict(cx, cy, cz)) mine |= (1u << k);
+        }
+        bits = mine | (uint32_t)quad_perm_i<0xB1>((int)mine);
+        bits |= (uint32_t)quad_perm_i<0x4E>((int)bits);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) feat[c] = 0.0f;
+        uint32_t rem = (ENARF_BWD_ABLATE & 4) ? 0u : bits;
+        while (true) {
+            const uint64_t bal = __ballot(rem != 0);
+            if (bal == 0) break;
+            const bool act = rem != 0;
+            const int k = act ? __builtin_ctz(rem) : 0;
+            rem &= rem - 1;
+            float F[13], Cn[12], lx, ly, lz, cx, cy, cz;
+            load_frames(S, k, F, Cn);
+            exact_local(F, px, py, pz, lx, ly, lz);
+            exact_canonical(Cn, F[12], lx, ly, lz, cx, cy, cz);
+            const float qx = (g4 == 1) ? cy : (g4 == 2) ? cz : cx;
+            const float qy = (g4 == 1) ? cz : (g4 == 2) ? cx : cy;
+            const Taps t = make_taps(qx, qy, T.H, T.W);
+            float sg = 1.0f;
+            if (act && g4 < 3) {
+                const float *mp = S.mask + (size_t)(3 * k + g4) * T.mplane;
+                float acc = mp[t.o00] * t.w00;
+                acc += mp[t.o01] * t.w01;
+                acc += mp[t.o10] * t.w10;
+                acc += mp[t.o11] * t.w11;
+                sg = sigmoidf_(acc);
+            }
+            const float wk = (quad_bcast_f<0>(sg) * quad_bcast_f<1>(sg)) * quad_bcast_f<2>(sg);
+            const Taps t0 = quad_bcast_taps<0>(t), t1 = quad_bcast_taps<1>(t), t2 = quad_bcast_taps<2>(t);
+            if (act) {
+                float s0[8], s1[8], s2[8];
+                const float *featg = S.feat + 8 * g4;
+                tap4(featg, t0, s0);
+                tap4(featg + T.fplane, t1, s1);
+                tap4(featg + 2 * T.fplane, t2, s2);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) feat[c] += ((s0[c] + s1[c]) + s2[c]) * wk;
+            }
+        }
+    }
+}
+
+// F3 + F4: MLP backward of one 16-sample tile (dz3v: this lane's dL/dz3 in MFMA layout), row export for the weight
+// gradients, and the second pass over the pairs: d part-probability and d feature texels
+__device__ __forceinline__ void bwd_backward_tile(const QueryCtx &S, const BwdTile &T, int b, float px, float py, float pz,
+                                                  uint32_t bits, const f32x4 a1[4], const f32x4 a2[4], const float x[8],
+                                                  float dz3v, int lane) {
+    const int g4 = lane & 3, j4 = lane >> 2;
+    const int mj = lane & 15, mg = lane >> 4;          // MFMA layout: point mj, k-group mg
+    f32x4 dz2[4], dz1[4];
+    float dxm[8];
+    mlp_bwd_tile_f32(T.l_wt, a1, a2, dz3v, lane, dz2, dz1, dxm);
+    // rows for the weight gradients: block of 16 rows of image b
+    unsigned int blk = 0;
+    if (lane == 0) blk = atomicAdd(T.row_blocks + b, 1u);
+    blk = (unsigned int)__builtin_amdgcn_readfirstlane((int)blk);
+    const size_t row = (size_t)b * T.rows_per_image + (size_t)blk * 16 + mj;
+    if (!(ENARF_BWD_ABLATE & 8)) {
+        f32x4 *rx = reinterpret_cast<f32x4 *>(T.rows_x + row * 32 + 8 * mg);
+        rx[0] = f32x4{x[0], x[1], x[2], x[3]};
+        rx[1] = f32x4{x[4], x[5], x[6], x[7]};
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob) {
+            *reinterpret_cast<f32x4 *>(T.rows_h1 + row * 64 + 16 * ob + 4 * mg) = a1[ob];
+            *reinterpret_cast<f32x4 *>(T.rows_h2 + row * 64 + 16 * ob + 4 * mg) = a2[ob];
+            *reinterpret_cast<f32x4 *>(T.rows_dz1 + row * 64 + 16 * ob + 4 * mg) = dz1[ob];
+            *reinterpret_cast<f32x4 *>(T.rows_dz2 + row * 64 + 16 * ob + 4 * mg) = dz2[ob];
+        }
+        T.rows_dz3[row * 4 + mg] = dz3v;
+    }
+    // d feature back in the gather layout
+    float dxg[8];
+    const int src2 = (g4 << 4) | j4;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) dxg[c] = __shfl(dxm[c], src2);
+
+    // ---- F4: second pass over the pairs: d part-probability and d feature texels
+    uint32_t rem = (ENARF_BWD_ABLATE & 4) ? 0u : bits;
+    while (true) {
+        const uint64_t bal = __ballot(rem != 0);
+        if (bal == 0) break;
+        const bool act = rem != 0;
+        const int k = act ? __builtin_ctz(rem) : 0;
+        rem &= rem - 1;
+        float F[13], Cn[12], lx, ly, lz, cx, cy, cz;
+        load_frames(S, k, F, Cn);
+        exact_local(F, px, py, pz, lx, ly, lz);
+        exact_canonical(Cn, F[12], lx, ly, lz, cx, cy, cz);
+        const float qx = (g4 == 1) ? cy : (g4 == 2) ? cz : cx;
+        const float qy = (g4 == 1) ? cz : (g4 == 2) ? cx : cy;
+        const Taps t = make_taps(qx, qy, T.H, T.W);
+        float sg = 1.0f;
+        if (act && g4 < 3) {
+            const float *mp = S.mask + (size_t)(3 * k + g4) * T.mplane;
+            float acc = mp[t.o00] * t.w00;
+            acc += mp[t.o01] * t.w01;
+            acc += mp[t.o10] * t.w10;
+            acc += mp[t.o11] * t.w11;
+            sg = sigmoidf_(acc);
+        }
+        const float wk = (quad_bcast_f<0>(sg) * quad_bcast_f<1>(sg)) * quad_bcast_f<2>(sg);
+        const Taps t0 = quad_bcast_taps<0>(t), t1 = quad_bcast_taps<1>(t), t2 = quad_bcast_taps<2>(t);
+        float dot = 0.0f;
+        if (act) {
+            float s0[8], s1[8], s2[8];
+            const float *featg = S.feat + 8 * g4;
+            tap4(featg, t0, s0);
+            tap4(featg + T.fplane, t1, s1);
+            tap4(featg + 2 * T.fplane, t2, s2);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) dot += dxg[c] * ((s0[c] + s1[c]) + s2[c]);
+        }
+        dot += quad_perm_f<0xB1>(dot);
+        dot += quad_perm_f<0x4E>(dot);                                  // d loss / d w_k, quad-uniform
+        if (act && g4 < 3 && !(ENARF_BWD_ABLATE & 2)) {   // w = s0 s1 s2, s = sigmoid(m): dw/dm_g = w (1 - s_g)
+            const float gm = dot * wk * (1.0f - sg);
+            float *gp = T.gmask + (size_t)(3 * k + g4) * T.mplane;
+            if (t.w00 != 0.0f) atomicAdd(gp + t.o00, t.w00 * gm);
+            if (t.w01 != 0.0f) atomicAdd(gp + t.o01, t.w01 * gm);
+            if (t.w10 != 0.0f) atomicAdd(gp + t.o10, t.w10 * gm);
+            if (t.w11 != 0.0f) atomicAdd(gp + t.o11, t.w11 * gm);
+        }
+        // every lane takes part (wave-uniform): inactive quads contribute empty rows
+        scatter_plane(T.gfeat, T.ttile, t0, wk, act, dxg, lane);
+        scatter_plane(T.gfeat + T.fplane, T.ttile, t1, wk, act, dxg, lane);
+        scatter_plane(T.gfeat + 2 * T.fplane, T.ttile, t2, wk, act, dxg, lane);
+    }
+}
+
 __global__ __launch_bounds__(256, kBwdWavesPerSimd) void render_bwd_kernel(const enarf_render_bwd_args a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -115,7 +274,12 @@ __global__ __launch_bounds__(256, kBwdWavesPerSimd) void render_bwd_kernel(const
     const int j4 = lane >> 2, g4 = lane & 3;
     const size_t mplane = (size_t)a.H * a.W, fplane = mplane * kFeat;
     int qslot = 0;
-    float *gfeat = nullptr, *gmask = nullptr;
+    BwdTile T;
+    T.H = a.H; T.W = a.W; T.mplane = mplane; T.fplane = fplane; T.l_wt = l_wt;
+    T.rows_x = a.rows_x; T.rows_h1 = a.rows_h1; T.rows_h2 = a.rows_h2;
+    T.rows_dz1 = a.rows_dz1; T.rows_dz2 = a.rows_dz2; T.rows_dz3 = a.rows_dz3;
+    T.rows_per_image = a.rows_per_image; T.row_blocks = a.row_blocks; T.ttile = ttile;
+    T.gfeat = nullptr; T.gmask = nullptr;
 
     while (cur >= 0) {
         if (tid == 0) rq.pop(qslot ^ 1);
@@ -138,8 +302,8 @@ __global__ __launch_bounds__(256, kBwdWavesPerSimd) void render_bwd_kernel(const
             }
             S.feat = a.feat_cl + (size_t)b * a.feat_batch_stride;
             S.mask = a.mask_planes + (size_t)b * a.mask_batch_stride;
-            gfeat = a.grad_feat_cl + (size_t)b * a.grad_feat_batch_stride;
-            gmask = a.grad_mask_planes + (size_t)b * a.grad_mask_batch_stride;
+            T.gfeat = a.grad_feat_cl + (size_t)b * a.grad_feat_batch_stride;
+            T.gmask = a.grad_mask_planes + (size_t)b * a.grad_mask_batch_stride;
             __syncthreads();
         }
         const RayRec rec = rq.rec(qslot);  // depth range, candidates and ray direction from the set-up pass (left in LDS by the pop)
@@ -157,58 +321,7 @@ __global__ __launch_bounds__(256, kBwdWavesPerSimd) void render_bwd_kernel(const
         const float px = exact_lerp(sx, ex, bi), py = exact_lerp(sy, ey, bi), pz = exact_lerp(sz, ez, bi);
         uint32_t bits;
         float feat[8];
-        {
-            uint32_t mine = 0;
-            for (int i0 = 0; i0 < ncand; i0 += 4) {
-                const int idx = i0 + g4;
-                const bool has = idx < ncand;
-                const int k = l_cand[has ? idx : 0];
-                float F[13], Cn[12], lx, ly, lz, cx, cy, cz;
-                load_frames(S, k, F, Cn);
-                exact_local(F, px, py, pz, lx, ly, lz);
-                exact_canonical(Cn, F[12], lx, ly, lz, cx, cy, cz);
-                if (active && has && in_unit_cube_incl(lx, ly, lz) && in_unit_cube_strict(cx, cy, cz)) mine |= (1u << k);
-            }
-            bits = mine | (uint32_t)quad_perm_i<0xB1>((int)mine);
-            bits |= (uint32_t)quad_perm_i<0x4E>((int)bits);
-#pragma unroll
-            for (int c = 0; c < 8; ++c) feat[c] = 0.0f;
-            uint32_t rem = (ENARF_BWD_ABLATE & 4) ? 0u : bits;
-            while (true) {
-                const uint64_t bal = __ballot(rem != 0);
-                if (bal == 0) break;
-                const bool act = rem != 0;
-                const int k = act ? __builtin_ctz(rem) : 0;
-                rem &= rem - 1;
-                float F[13], Cn[12], lx, ly, lz, cx, cy, cz;
-                load_frames(S, k, F, Cn);
-                exact_local(F, px, py, pz, lx, ly, lz);
-                exact_canonical(Cn, F[12], lx, ly, lz, cx, cy, cz);
-                const float qx = (g4 == 1) ? cy : (g4 == 2) ? cz : cx;
-                const float qy = (g4 == 1) ? cz : (g4 == 2) ? cx : cy;
-                const Taps t = make_taps(qx, qy, a.H, a.W);
-                float sg = 1.0f;
-                if (act && g4 < 3) {
-                    const float *mp = S.mask + (size_t)(3 * k + g4) * mplane;
-                    float acc = mp[t.o00] * t.w00;
-                    acc += mp[t.o01] * t.w01;
-                    acc += mp[t.o10] * t.w10;
-                    acc += mp[t.o11] * t.w11;
-                    sg = sigmoidf_(acc);
-                }
-                const float wk = (quad_bcast_f<0>(sg) * quad_bcast_f<1>(sg)) * quad_bcast_f<2>(sg);
-                const Taps t0 = quad_bcast_taps<0>(t), t1 = quad_bcast_taps<1>(t), t2 = quad_bcast_taps<2>(t);
-                if (act) {
-                    float s0[8], s1[8], s2[8];
-                    const float *featg = S.feat + 8 * g4;
-                    tap4(featg, t0, s0);
-                    tap4(featg + fplane, t1, s1);
-                    tap4(featg + 2 * fplane, t2, s2);
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) feat[c] += ((s0[c] + s1[c]) + s2[c]) * wk;
-                }
-            }
-        }
+        bwd_gather_tile(S, T, l_cand, ncand, px, py, pz, active, lane, bits, feat);
         const bool ran = __ballot(bits != 0) != 0;      // wave-uniform
         f32x4 a1[4], a2[4], o;
         float x[8];
@@ -270,84 +383,7 @@ __global__ __launch_bounds__(256, kBwdWavesPerSimd) void render_bwd_kernel(const
             const int mj = lane & 15, mg = lane >> 4;          // MFMA layout: point mj, k-group mg
             const int ms = min(wave * Tf + mj, Nf - 1);
             const float dz3v = (mj < Tf) ? l_dz3[mg * 64 + ms] : 0.0f;
-            f32x4 dz2[4], dz1[4];
-            float dxm[8];
-            mlp_bwd_tile_f32(l_wt, a1, a2, dz3v, lane, dz2, dz1, dxm);
-            // rows for the weight gradients: block of 16 rows of image b
-            unsigned int blk = 0;
-            if (lane == 0) blk = atomicAdd(a.row_blocks + b, 1u);
-            blk = (unsigned int)__builtin_amdgcn_readfirstlane((int)blk);
-            const size_t row = (size_t)b * a.rows_per_image + (size_t)blk * 16 + mj;
-            if (!(ENARF_BWD_ABLATE & 8)) {
-                f32x4 *rx = reinterpret_cast<f32x4 *>(a.rows_x + row * 32 + 8 * mg);
-                rx[0] = f32x4{x[0], x[1], x[2], x[3]};
-                rx[1] = f32x4{x[4], x[5], x[6], x[7]};
-#pragma unroll
-                for (int ob = 0; ob < 4; ++ob) {
-                    *reinterpret_cast<f32x4 *>(a.rows_h1 + row * 64 + 16 * ob + 4 * mg) = a1[ob];
-                    *reinterpret_cast<f32x4 *>(a.rows_h2 + row * 64 + 16 * ob + 4 * mg) = a2[ob];
-                    *reinterpret_cast<f32x4 *>(a.rows_dz1 + row * 64 + 16 * ob + 4 * mg) = dz1[ob];
-                    *reinterpret_cast<f32x4 *>(a.rows_dz2 + row * 64 + 16 * ob + 4 * mg) = dz2[ob];
-                }
-                a.rows_dz3[row * 4 + mg] = dz3v;
-            }
-            // d feature back in the gather layout
-            float dxg[8];
-            const int src2 = (g4 << 4) | j4;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) dxg[c] = __shfl(dxm[c], src2);
-
-            // ---- F4: second pass over the pairs: d part-probability and d feature texels
-            uint32_t rem = (ENARF_BWD_ABLATE & 4) ? 0u : bits;
-            while (true) {
-                const uint64_t bal = __ballot(rem != 0);
-                if (bal == 0) break;
-                const bool act = rem != 0;
-                const int k = act ? __builtin_ctz(rem) : 0;
-                rem &= rem - 1;
-                float F[13], Cn[12], lx, ly, lz, cx, cy, cz;
-                load_frames(S, k, F, Cn);
-                exact_local(F, px, py, pz, lx, ly, lz);
-                exact_canonical(Cn, F[12], lx, ly, lz, cx, cy, cz);
-                const float qx = (g4 == 1) ? cy : (g4 == 2) ? cz : cx;
-                const float qy = (g4 == 1) ? cz : (g4 == 2) ? cx : cy;
-                const Taps t = make_taps(qx, qy, a.H, a.W);
-                float sg = 1.0f;
-                if (act && g4 < 3) {
-                    const float *mp = S.mask + (size_t)(3 * k + g4) * mplane;
-                    float acc = mp[t.o00] * t.w00;
-                    acc += mp[t.o01] * t.w01;
-                    acc += mp[t.o10] * t.w10;
-                    acc += mp[t.o11] * t.w11;
-                    sg = sigmoidf_(acc);
-                }
-                const float wk = (quad_bcast_f<0>(sg) * quad_bcast_f<1>(sg)) * quad_bcast_f<2>(sg);
-                const Taps t0 = quad_bcast_taps<0>(t), t1 = quad_bcast_taps<1>(t), t2 = quad_bcast_taps<2>(t);
-                float dot = 0.0f;
-                if (act) {
-                    float s0[8], s1[8], s2[8];
-                    const float *featg = S.feat + 8 * g4;
-                    tap4(featg, t0, s0);
-                    tap4(featg + fplane, t1, s1);
-                    tap4(featg + 2 * fplane, t2, s2);
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) dot += dxg[c] * ((s0[c] + s1[c]) + s2[c]);
-                }
-                dot += quad_perm_f<0xB1>(dot);
-                dot += quad_perm_f<0x4E>(dot);                                  // d loss / d w_k, quad-uniform
-                if (act && g4 < 3 && !(ENARF_BWD_ABLATE & 2)) {   // w = s0 s1 s2, s = sigmoid(m): dw/dm_g = w (1 - s_g)
-                    const float gm = dot * wk * (1.0f - sg);
-                    float *gp = gmask + (size_t)(3 * k + g4) * mplane;
-                    if (t.w00 != 0.0f) atomicAdd(gp + t.o00, t.w00 * gm);
-                    if (t.w01 != 0.0f) atomicAdd(gp + t.o01, t.w01 * gm);
-                    if (t.w10 != 0.0f) atomicAdd(gp + t.o10, t.w10 * gm);
-                    if (t.w11 != 0.0f) atomicAdd(gp + t.o11, t.w11 * gm);
-                }
-                // every lane takes part (wave-uniform): inactive quads contribute empty rows
-                scatter_plane(gfeat, ttile, t0, wk, act, dxg, lane);
-                scatter_plane(gfeat + fplane, ttile, t1, wk, act, dxg, lane);
-                scatter_plane(gfeat + 2 * fplane, ttile, t2, wk, act, dxg, lane);
-            }
+            bwd_backward_tile(S, T, b, px, py, pz, bits, a1, a2, x, dz3v, lane);
         }
         // the next ray's first barrier orders this ray's LDS reads (l_dz3, l_fh) before their next writes
         __syncthreads();
