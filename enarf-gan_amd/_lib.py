@@ -79,6 +79,20 @@ class RenderBwdArgs(C.Structure):
     ]
 
 
+class QueryBwdArgs(C.Structure):
+    _fields_ = [
+        ("B", C.c_int), ("P", C.c_int), ("H", C.c_int), ("W", C.c_int), ("N", C.c_longlong),
+        ("points", _f32p), ("parts", _f32p), ("canonical_pose", _f32p),
+        ("feat_cl", _f32p), ("feat_batch_stride", C.c_longlong),
+        ("mask_planes", _f32p), ("mask_batch_stride", C.c_longlong),
+        ("mlp_pack", _f32p), ("g_density", _f32p), ("g_color", _f32p),
+        ("grad_feat_cl", _f32p), ("grad_feat_batch_stride", C.c_longlong),
+        ("grad_mask_planes", _f32p), ("grad_mask_batch_stride", C.c_longlong),
+        ("rows_x", _f32p), ("rows_h1", _f32p), ("rows_h2", _f32p), ("rows_dz1", _f32p), ("rows_dz2", _f32p),
+        ("rows_dz3", _f32p), ("rows_per_image", C.c_longlong), ("row_blocks", _f32p),
+    ]
+
+
 class WeightGradArgs(C.Structure):
     _fields_ = [
         ("B", C.c_int),
@@ -100,6 +114,9 @@ class PrepareBwdArgs(C.Structure):
 # every symbol include/enarf_hip.h declares: name -> (restype, argtypes)
 SIGNATURES = {
     "enarf_abi_version": (C.c_int, []),
+    "enarf_version": (C.c_int, []),
+    "enarf_query_bwd_rows_per_image": (C.c_longlong, [C.c_longlong]),
+    "enarf_query_bwd": (C.c_int, [C.POINTER(QueryBwdArgs), C.c_void_p]),
     "enarf_last_error": (C.c_char_p, []),
     "enarf_triplane_sample_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
     "enarf_triplane_sample_bwd_workspace_bytes": (C.c_size_t, [C.c_int] * 4),

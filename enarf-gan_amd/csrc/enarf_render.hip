@@ -859,6 +859,7 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
 using namespace enarf;
 
 extern "C" int enarf_abi_version(void) { return ENARF_ABI_VERSION; }
+extern "C" int enarf_version(void) { return ENARF_ABI_VERSION; }
 extern "C" const char *enarf_last_error(void) { return host::last_error(); }
 extern "C" size_t enarf_mlp_pack_bytes(void) { return kPackBytes; }
 

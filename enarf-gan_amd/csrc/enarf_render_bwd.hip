@@ -248,6 +248,24 @@ __device__ __forceinline__ void bwd_backward_tile(const QueryCtx &S, const BwdTi
     }
 }
 
+// stage image b's MLP weights (forward + transposed sections), biases and part / canonical frames into LDS
+__device__ __forceinline__ void bwd_stage_image(const void *mlp_pack, const float *parts, const float *canonical_pose, int b,
+                                                int P, float *l_w, float *l_bias, float *l_wt, float *l_parts,
+                                                float *l_canon, int tid) {
+    const float *pf = reinterpret_cast<const float *>(reinterpret_cast<const char *>(mlp_pack) + (size_t)b * kPackBytes);
+    const float *pt = reinterpret_cast<const float *>(reinterpret_cast<const char *>(pf) + kPackTOff);
+    for (int i = tid; i < PK_B1 / 4; i += 256) reinterpret_cast<f32x4 *>(l_w)[i] = reinterpret_cast<const f32x4 *>(pf)[i];
+    for (int i = tid; i < 144; i += 256) l_bias[i] = pf[PK_B1 + i];
+    for (int i = tid; i < PKT_FLOATS / 4; i += 256) reinterpret_cast<f32x4 *>(l_wt)[i] = reinterpret_cast<const f32x4 *>(pt)[i];
+    const float *parts_b = parts + (size_t)b * P * kPartStride;
+    for (int i = tid; i < P * kPartStride; i += 256)
+        l_parts[(i / kPartStride) * kLdsPartStride + (i % kPartStride)] = parts_b[i];
+    for (int i = tid; i < P * 12; i += 256) {
+        const int k = i / 12, e = i % 12;
+        l_canon[i] = (e < 9) ? canonical_pose[k * 16 + (e / 3) * 4 + (e % 3)] : canonical_pose[k * 16 + (e - 9) * 4 + 3];
+    }
+}
+
 __global__ __launch_bounds__(256, kBwdWavesPerSimd) void render_bwd_kernel(const enarf_render_bwd_args a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -288,18 +306,7 @@ __global__ __launch_bounds__(256, kBwdWavesPerSimd) void render_bwd_kernel(const
         if (nb != b) {   // (re)stage the image's weights (forward + transposed), biases and frames
             if (b >= 0) __syncthreads();
             b = nb;
-            const float *pf = reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.mlp_pack) + (size_t)b * kPackBytes);
-            const float *pt = reinterpret_cast<const float *>(reinterpret_cast<const char *>(pf) + kPackTOff);
-            for (int i = tid; i < PK_B1 / 4; i += 256) reinterpret_cast<f32x4 *>(l_w)[i] = reinterpret_cast<const f32x4 *>(pf)[i];
-            for (int i = tid; i < 144; i += 256) l_bias[i] = pf[PK_B1 + i];
-            for (int i = tid; i < PKT_FLOATS / 4; i += 256) reinterpret_cast<f32x4 *>(l_wt)[i] = reinterpret_cast<const f32x4 *>(pt)[i];
-            const float *parts_b = a.parts + (size_t)b * P * kPartStride;
-            for (int i = tid; i < P * kPartStride; i += 256)
-                l_parts[(i / kPartStride) * kLdsPartStride + (i % kPartStride)] = parts_b[i];
-            for (int i = tid; i < P * 12; i += 256) {
-                const int k = i / 12, e = i % 12;
-                l_canon[i] = (e < 9) ? a.canonical_pose[k * 16 + (e / 3) * 4 + (e % 3)] : a.canonical_pose[k * 16 + (e - 9) * 4 + 3];
-            }
+            bwd_stage_image(a.mlp_pack, a.parts, a.canonical_pose, b, P, l_w, l_bias, l_wt, l_parts, l_canon, tid);
             S.feat = a.feat_cl + (size_t)b * a.feat_batch_stride;
             S.mask = a.mask_planes + (size_t)b * a.mask_batch_stride;
             T.gfeat = a.grad_feat_cl + (size_t)b * a.grad_feat_batch_stride;
@@ -388,6 +395,93 @@ __global__ __launch_bounds__(256, kBwdWavesPerSimd) void render_bwd_kernel(const
         // the next ray's first barrier orders this ray's LDS reads (l_dz3, l_fh) before their next writes
         __syncthreads();
         cur = next_ray;
+    }
+}
+
+// ---- backward of the point query (a9): dL/d density, dL/d colour -> tri-plane gradients + rows for the weight gradients ----
+// Same tile stages as the ray kernel, on tiles of 64 consecutive points of one image; every part is a candidate; the
+// head backward is per point (no compositing): density = MyReLU(h3) * 10 * any_valid, colour = tanh(h0..2). Points
+// without a valid part still run the MLP on a zero feature (narf.py:255-268), so their colour gradient reaches the
+// weights and biases, as in the reference.
+__global__ __launch_bounds__(256, kBwdWavesPerSimd) void query_bwd_kernel(const enarf_query_bwd_args a, long long tiles) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.y;
+    const int P = a.P;
+    const long long N = a.N;
+    float *l_w = lds, *l_bias = l_w + PK_B1, *l_wt = l_bias + 144, *l_parts = l_wt + PKT_FLOATS;
+    float *l_canon = l_parts + P * kLdsPartStride, *scratch = l_canon + P * kLdsCanonStride;
+    QueryCtx S;
+    S.mlp = l_w; S.mlp_h = nullptr; S.bias = l_bias; S.parts = l_parts; S.canon = l_canon;
+    S.H = a.H; S.W = a.W; S.P = P; S.mult_w = 0; S.ablate = 0;
+    S.feat = a.feat_cl + (size_t)b * a.feat_batch_stride;
+    S.mask = a.mask_planes + (size_t)b * a.mask_batch_stride;
+    int *l_cand = reinterpret_cast<int *>(scratch + SB_CAND);
+    float *l_fh = scratch + SB_FH, *l_dz3 = scratch + SB_DZ3;
+    uint32_t *l_fbits = reinterpret_cast<uint32_t *>(scratch + SB_FBITS);
+    BwdTile T;
+    T.H = a.H; T.W = a.W; T.mplane = (size_t)a.H * a.W; T.fplane = T.mplane * kFeat; T.l_wt = l_wt;
+    T.rows_x = a.rows_x; T.rows_h1 = a.rows_h1; T.rows_h2 = a.rows_h2;
+    T.rows_dz1 = a.rows_dz1; T.rows_dz2 = a.rows_dz2; T.rows_dz3 = a.rows_dz3;
+    T.rows_per_image = a.rows_per_image; T.row_blocks = a.row_blocks;
+    T.ttile = scratch + kScratchFloats + wave * kTTile;
+    T.gfeat = a.grad_feat_cl + (size_t)b * a.grad_feat_batch_stride;
+    T.gmask = a.grad_mask_planes + (size_t)b * a.grad_mask_batch_stride;
+    bwd_stage_image(a.mlp_pack, a.parts, a.canonical_pose, b, P, l_w, l_bias, l_wt, l_parts, l_canon, tid);
+    if (tid < P) l_cand[tid] = tid;
+    __syncthreads();
+    const float *pp = a.points + (size_t)b * 3 * N;
+    const int j4 = lane >> 2, g4 = lane & 3;
+    for (long long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const long long i = tile * 64 + wave * 16 + j4;
+        const bool active = i < N;
+        const long long ic = active ? i : N - 1;
+        const float px = pp[ic], py = pp[N + ic], pz = pp[2 * N + ic];
+        uint32_t bits;
+        float feat[8];
+        bwd_gather_tile(S, T, l_cand, P, px, py, pz, active, lane, bits, feat);
+        const bool ran = tile * 64 + wave * 16 < N;        // wave-uniform: the tile has points (valid part or not)
+        f32x4 a1[4], a2[4], o;
+        float x[8];
+        if (ran) {
+            const int src = ((lane & 15) << 2) | (lane >> 4);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) x[c] = __shfl(feat[c], src);
+            mlp_tile_f32_keep(l_w, l_bias, x, lane, a1, a2, o);
+        } else {
+            o = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+        if (lane < 16) {
+            const int io = wave * 16 + lane;
+            l_fh[io] = o[0]; l_fh[64 + io] = o[1]; l_fh[128 + io] = o[2]; l_fh[192 + io] = o[3];
+        }
+        if (g4 == 0) l_fbits[wave * 16 + j4] = active ? bits : 0u;
+        __syncthreads();
+        if (wave == 0) {   // head backward, lane = point of the tile
+            const long long pi = tile * 64 + lane;
+            const bool in = pi < N;
+            const size_t po = (size_t)b * N + (in ? pi : 0);
+            const float gD = (in && a.g_density) ? a.g_density[po] : 0.0f;
+            const float gC0 = (in && a.g_color) ? a.g_color[((size_t)b * 3 + 0) * N + (in ? pi : 0)] : 0.0f;
+            const float gC1 = (in && a.g_color) ? a.g_color[((size_t)b * 3 + 1) * N + (in ? pi : 0)] : 0.0f;
+            const float gC2 = (in && a.g_color) ? a.g_color[((size_t)b * 3 + 2) * N + (in ? pi : 0)] : 0.0f;
+            const uint32_t sb = l_fbits[lane];
+            const float h0 = l_fh[lane], h1 = l_fh[64 + lane], h2 = l_fh[128 + lane], h3 = l_fh[192 + lane];
+            const float cr = tanhf(h0), cg = tanhf(h1), cb = tanhf(h2);
+            // density = MyReLU(h3) * 10 * any_valid; MyReLU backward: slope 0.1 for x < 0 when the gradient is negative
+            const float gy = sb ? gD * 10.0f : 0.0f;
+            const float gx = (h3 >= 0.0f) ? gy : ((gy < 0.0f) ? 0.1f * gy : 0.0f);
+            l_dz3[192 + lane] = gx * styled_act_grad(h3);
+            l_dz3[lane] = (1.0f - cr * cr) * gC0 * styled_act_grad(h0);
+            l_dz3[64 + lane] = (1.0f - cg * cg) * gC1 * styled_act_grad(h1);
+            l_dz3[128 + lane] = (1.0f - cb * cb) * gC2 * styled_act_grad(h2);
+        }
+        __syncthreads();
+        if (ran) {
+            const int mj = lane & 15, mg = lane >> 4;
+            const float dz3v = l_dz3[mg * 64 + wave * 16 + mj];
+            bwd_backward_tile(S, T, b, px, py, pz, bits, a1, a2, x, dz3v, lane);
+        }
+        __syncthreads();     // l_fh / l_dz3 are rewritten by the next tile
     }
 }
 
@@ -637,6 +731,35 @@ extern "C" int enarf_render_bwd(const enarf_render_bwd_args *args, enarf_stream_
     if (wgs > total) wgs = total;
     hipLaunchKernelGGL(render_bwd_kernel, dim3((unsigned)wgs), dim3(256), (size_t)bwd_lds_floats(a.P) * 4, st, a);
     return host::check_launch("enarf_render_bwd");
+}
+
+extern "C" long long enarf_query_bwd_rows_per_image(long long N) {
+    if (N <= 0) return 0;
+    return ((N + 15) / 16) * 16;       // one row per point, in 16-row tiles
+}
+
+extern "C" int enarf_query_bwd(const enarf_query_bwd_args *args, enarf_stream_t stream) {
+    if (!args) return host::fail(ENARF_ERR_ARG, "enarf_query_bwd: args is null");
+    const enarf_query_bwd_args &a = *args;
+    if (a.B <= 0 || a.B > 65535 || a.N < 0 || a.P <= 0 || a.P > ENARF_MAX_PARTS || a.H <= 0 || a.W <= 0)
+        return host::fail(ENARF_ERR_ARG, "enarf_query_bwd: bad sizes");
+    if (!a.points || !a.parts || !a.canonical_pose || !a.feat_cl || !a.mask_planes || !a.mlp_pack || !a.grad_feat_cl ||
+        !a.grad_mask_planes || !a.rows_x || !a.rows_h1 || !a.rows_h2 || !a.rows_dz1 || !a.rows_dz2 || !a.rows_dz3 || !a.row_blocks)
+        return host::fail(ENARF_ERR_ARG, "enarf_query_bwd: null pointer");
+    if (a.rows_per_image < enarf_query_bwd_rows_per_image(a.N))
+        return host::fail(ENARF_ERR_ARG, "enarf_query_bwd: rows_per_image %lld < %lld", a.rows_per_image,
+                          enarf_query_bwd_rows_per_image(a.N));
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(a.row_blocks, 0, sizeof(unsigned int) * a.B, st);
+    if (e != hipSuccess) return host::fail((int)e, "enarf_query_bwd: hipMemsetAsync failed: %s", hipGetErrorString(e));
+    if (a.N == 0) return 0;
+    const int num_cus = device_cus();
+    if (num_cus <= 0) return host::fail((int)hipGetLastError(), "enarf_query_bwd: cannot query the device");
+    const long long tiles = (a.N + 63) / 64;
+    long long per_image = ((long long)num_cus * kBwdWavesPerSimd + a.B - 1) / a.B;
+    if (per_image > tiles) per_image = tiles;
+    hipLaunchKernelGGL(query_bwd_kernel, dim3((unsigned)per_image, a.B), dim3(256), (size_t)bwd_lds_floats(a.P) * 4, st, a, tiles);
+    return host::check_launch("enarf_query_bwd");
 }
 
 extern "C" int enarf_triplane_unpack_add(const float *grad_feat_cl, float *grad_tri_nchw, int B, int channels_total,

@@ -381,9 +381,7 @@ def render_bwd(image_coord, inv_intrinsics, parts, canonical_pose, tri_nchw, fea
     mstride, fstride = _plane_strides(tri, feat_cl, B)
     dev = coord.device
     rows = int(lib.enarf_render_bwd_rows_per_image(n, Nf))
-    bufs = {k: torch.empty(B, rows, w, dtype=torch.float32, device=dev)
-            for k, w in (("x", 32), ("h1", 64), ("h2", 64), ("dz1", 64), ("dz2", 64), ("dz3", 4))}
-    blocks = torch.zeros(B, dtype=torch.int32, device=dev)
+    bufs, blocks = _row_buffers(B, rows, dev)
     grad_tri = torch.zeros_like(tri)
     gfeat = torch.zeros_like(feat_cl)
     a = _lib.RenderBwdArgs()
@@ -410,7 +408,19 @@ def render_bwd(image_coord, inv_intrinsics, parts, canonical_pose, tri_nchw, fea
     _lib.check(lib.enarf_render_bwd(C.byref(a), _stream(dev)), "enarf_render_bwd")
     _lib.check(lib.enarf_triplane_unpack_add(_p(gfeat), _p(grad_tri), grad_tri.shape[0], Ct, H, W, _stream(dev)),
                "enarf_triplane_unpack_add")
-    # weight gradients per image: dW'_l = dZ_l^T H_{l-1}, db_l = column sums of dZ_l, from the rows the kernel wrote
+    dW, db = _weight_grad(bufs, blocks, B, rows, dev)
+    return grad_tri, dW, db
+
+
+def _row_buffers(B: int, rows: int, dev: torch.device):
+    bufs = {k: torch.empty(B, rows, w, dtype=torch.float32, device=dev)
+            for k, w in (("x", 32), ("h1", 64), ("h2", 64), ("dz1", 64), ("dz2", 64), ("dz3", 4))}
+    return bufs, torch.zeros(B, dtype=torch.int32, device=dev)
+
+
+def _weight_grad(bufs, blocks, B: int, rows: int, dev: torch.device):
+    """dW'_l = dZ_l^T H_{l-1} per image and db_l = column sums of dZ_l, from the rows a backward kernel exported."""
+    lib = _lib.load()
     dW = [torch.empty(B, 64, 32, device=dev), torch.empty(B, 64, 64, device=dev), torch.empty(B, 4, 64, device=dev)]
     dbb = [torch.empty(B, 64, device=dev), torch.empty(B, 64, device=dev), torch.empty(B, 4, device=dev)]
     w = _lib.WeightGradArgs()
@@ -422,7 +432,44 @@ def render_bwd(image_coord, inv_intrinsics, parts, canonical_pose, tri_nchw, fea
     wws = torch.empty(int(lib.enarf_weight_grad_workspace_bytes(B, rows)) // 4, dtype=torch.float32, device=dev)
     w.workspace = _p(wws)
     _lib.check(lib.enarf_weight_grad(C.byref(w), _stream(dev)), "enarf_weight_grad")
-    db = [t.sum(dim=0) for t in dbb]
+    return dW, [t.sum(dim=0) for t in dbb]
+
+
+def query_bwd(points, parts, canonical_pose, tri_nchw, feat_cl, mlp_pack, g_density, g_color):
+    """Backward of query_fwd w.r.t. the tri-plane and the per-image demodulated MLP weights / biases.
+
+    points (B,3,N); g_density (B,1,N) or None; g_color (B,3,N) or None. Returns (grad_tri, dW [3 x (B,out,in)], db)."""
+    lib = _lib.load()
+    pts = _dev_f32(points, "points")
+    B, _, N = pts.shape
+    P = parts.shape[1]
+    tri = _dev_f32(tri_nchw, "tri_plane")
+    Ct, H, W = tri.shape[1:]
+    mstride, fstride = _plane_strides(tri, feat_cl, B)
+    dev = pts.device
+    rows = max(int(lib.enarf_query_bwd_rows_per_image(N)), 16)
+    bufs, blocks = _row_buffers(B, rows, dev)
+    grad_tri = torch.zeros_like(tri)
+    gfeat = torch.zeros_like(feat_cl)
+    a = _lib.QueryBwdArgs()
+    a.B, a.P, a.H, a.W, a.N = B, P, H, W, N
+    a.points, a.parts = _p(pts) if N else _p(torch.zeros(1, device=dev)), _p(parts)
+    a.canonical_pose = _p(_dev_f32(canonical_pose, "canonical_pose"))
+    a.feat_cl, a.feat_batch_stride = _p(feat_cl), fstride
+    a.mask_planes, a.mask_batch_stride = tri.data_ptr() + PLANE_CH * H * W * 4, mstride
+    a.mlp_pack = _p(mlp_pack)
+    gd = None if g_density is None else _dev_f32(g_density, "g_density").reshape(B, N)
+    gc = None if g_color is None else _dev_f32(g_color, "g_color").reshape(B, 3, N)
+    a.g_density, a.g_color = (_p(gd) if N else None), (_p(gc) if N else None)
+    a.grad_feat_cl, a.grad_feat_batch_stride = _p(gfeat), fstride
+    a.grad_mask_planes, a.grad_mask_batch_stride = grad_tri.data_ptr() + PLANE_CH * H * W * 4, mstride
+    a.rows_x, a.rows_h1, a.rows_h2 = _p(bufs["x"]), _p(bufs["h1"]), _p(bufs["h2"])
+    a.rows_dz1, a.rows_dz2, a.rows_dz3 = _p(bufs["dz1"]), _p(bufs["dz2"]), _p(bufs["dz3"])
+    a.rows_per_image, a.row_blocks = rows, _p(blocks)
+    _lib.check(lib.enarf_query_bwd(C.byref(a), _stream(dev)), "enarf_query_bwd")
+    _lib.check(lib.enarf_triplane_unpack_add(_p(gfeat), _p(grad_tri), grad_tri.shape[0], Ct, H, W, _stream(dev)),
+               "enarf_triplane_unpack_add")
+    dW, db = _weight_grad(bufs, blocks, B, rows, dev)
     return grad_tri, dW, db
 
 

@@ -50,6 +50,7 @@ extern "C" {
 typedef void *enarf_stream_t;
 
 int         enarf_abi_version(void);
+int         enarf_version(void);          /* the same number under the name SURVEY.md 8(b) lists */
 const char *enarf_last_error(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -254,6 +255,30 @@ typedef struct {
 
 long long enarf_render_bwd_rows_per_image(int n, int Nf);
 int enarf_render_bwd(const enarf_render_bwd_args *args, enarf_stream_t stream);
+
+/* Backward of enarf_query_fwd (a9: TriPlaneNARF.calc_density_and_color_from_camera_coord_v2, models/narf.py:176-275)
+ * w.r.t. the tri-plane and the per-image demodulated MLP weights: given dL/d density (B,1,N) and dL/d color (B,3,N)
+ * (either may be NULL) it adds into grad_feat_cl / grad_mask_planes and exports the rows enarf_weight_grad consumes.
+ * The points carry no gradient (the reference detaches nothing here, but every caller of the query samples points from
+ * non-differentiable poses). multiply_density_with_triplane_wieght is not differentiable here (as in enarf_render_bwd). */
+typedef struct {
+    int B, P, H, W;
+    long long N;
+    const float *points;                  /* (B, 3, N) */
+    const float *parts, *canonical_pose;  /* as enarf_query_args */
+    const float *feat_cl; long long feat_batch_stride;
+    const float *mask_planes; long long mask_batch_stride;
+    const void *mlp_pack;
+    const float *g_density;               /* (B, 1, N) or NULL */
+    const float *g_color;                 /* (B, 3, N) or NULL */
+    float *grad_feat_cl; long long grad_feat_batch_stride;      /* (B|1, 3, H, W, 32), zero-filled by the caller */
+    float *grad_mask_planes; long long grad_mask_batch_stride;  /* &grad_tri[0][96][0][0], zero-filled by the caller */
+    float *rows_x, *rows_h1, *rows_h2, *rows_dz1, *rows_dz2, *rows_dz3;   /* (B, rows_per_image, 32|64|64|64|64|4) */
+    long long rows_per_image;             /* >= enarf_query_bwd_rows_per_image(N) */
+    unsigned int *row_blocks;             /* device (B,): 16-row blocks written per image (zeroed by the call) */
+} enarf_query_bwd_args;
+long long enarf_query_bwd_rows_per_image(long long N);
+int enarf_query_bwd(const enarf_query_bwd_args *args, enarf_stream_t stream);
 
 /* Weight gradients of the per-image (demodulated) StyledMLP from the rows enarf_render_bwd exported:
  *   dW1 (B,64,32) = dZ1^T X, dW2 (B,64,64) = dZ2^T H1, dW3 (B,4,64) = dZ3^T H2, db_l (B, out) = column sums of dZ_l,

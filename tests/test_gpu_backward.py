@@ -108,3 +108,44 @@ def test_render_backward_matches_reference_gradients(name):
         assert_close(db[l].cpu(), g[f"grad_layers.{l}.bias"].reshape(-1), f"d bias {l}", 1e-3)
         for leaf in ("conv.weight", "conv.modulation.weight", "conv.modulation.bias"):
             assert_close(pg[f"layers.{l}.{leaf}"].cpu(), g[f"grad_layers.{l}.{leaf}"], f"d layers.{l}.{leaf}", 1e-3)
+
+
+@pytest.mark.parametrize("B,style_dim,N", [(1, 20, 1000), (2, 256, 333)])
+def test_query_backward_matches_oracle_autograd(B, style_dim, N):
+    """enarf_query_bwd (a9) against autograd through the oracle's query: points inside and outside the part cubes (the
+    outside ones still send their colour gradient to the MLP through a zero feature), ragged N, batch 2."""
+    from enarf_gan_amd import ops
+    sc = Scene(32, B, "center+head", style_dim)
+    ds = DeviceScene(sc)
+    s = sc.raw
+    g = torch.Generator().manual_seed(11)
+    # points around the joints (mostly inside some cube) plus a fifth far away (no valid part)
+    jp = sc.pose_scaled[:, :, :3, 3]                                   # (B, P, 3)
+    pick = torch.randint(0, jp.shape[1], (B, N), generator=g)
+    pts = torch.gather(jp, 1, pick[..., None].expand(-1, -1, 3)).permute(0, 2, 1).contiguous()
+    pts = pts + 0.25 * torch.randn(B, 3, N, generator=g)
+    pts[:, :, ::5] += 50.0
+    gD, gC = torch.randn(B, 1, N, generator=g), torch.randn(B, 3, N, generator=g)
+
+    tri = s["tri_plane"].clone().requires_grad_(True)
+    mlp = {k: v.clone().requires_grad_(True) for k, v in s["mlp"].items() if "noise" not in k}
+    z = s["z_rend"].clone().requires_grad_(True)
+    den, col, valid = O.query(pts, sc.pose_scaled, sc.scale, sc.cpose, tri, O.modulated_weights(mlp, z))
+    assert 0.05 < float(valid.any(dim=1).float().mean()) < 0.95
+    keys = sorted(mlp)
+    grads = torch.autograd.grad((den * gD).sum() + (col * gC).sum(), [tri, z] + [mlp[k] for k in keys])
+    o_tri, o_z, o_mlp = grads[0], grads[1], dict(zip(keys, grads[2:]))
+
+    grad_tri, dW, db = ops.query_bwd(pts.cuda(), ds.parts, ds.cpose, ds.tri, ds.feat_cl, ds.pack, gD.cuda(), gC.cuda())
+    pg, dz = ops.prepare_bwd(s["z_rend"].cuda(), ds.mlp, dW)
+    assert_close(grad_tri[:, :96].cpu(), o_tri[:, :96], "d loss / d feature planes", 1e-3)
+    assert_close(grad_tri[:, 96:].cpu(), o_tri[:, 96:], "d loss / d part-probability planes", 1e-3)
+    for l in range(3):
+        assert_close(db[l].cpu(), o_mlp[f"layers.{l}.bias"].reshape(-1), f"d bias {l}", 1e-3)
+        for leaf in ("conv.weight", "conv.modulation.weight", "conv.modulation.bias"):
+            assert_close(pg[f"layers.{l}.{leaf}"].cpu(), o_mlp[f"layers.{l}.{leaf}"], f"d layers.{l}.{leaf}", 1e-3)
+    assert_close(dz.cpu(), o_z, "d z_rend", 1e-3)
+    # colour gradient alone, density gradient alone
+    only_c = ops.query_bwd(pts.cuda(), ds.parts, ds.cpose, ds.tri, ds.feat_cl, ds.pack, None, gC.cuda())
+    only_d = ops.query_bwd(pts.cuda(), ds.parts, ds.cpose, ds.tri, ds.feat_cl, ds.pack, gD.cuda(), None)
+    assert_close((only_c[0] + only_d[0]).cpu(), o_tri, "linearity in the output gradients", 1e-3)
