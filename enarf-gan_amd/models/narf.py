@@ -217,19 +217,66 @@ class TriPlaneNARF(nn.Module):
                                                     ray_direction: Optional[torch.Tensor], model_input: Dict):
         """models/narf.py:176-211: position (B,3,n) camera coords, pose_to_camera (B,P,4,4) part frames whose
         translation is already x coordinate_scale (as render / create_mesh pass it) -> density (B,1,n), colour (B,3,n)."""
-        tri, feat_cl = self._tri_plane_pair(model_input)
         B, P = pose_to_camera.shape[:2]
+        if pose_to_camera.requires_grad or position.requires_grad:
+            raise NotImplementedError("Currently pose and positions should not be differentiable")
         parts = torch.zeros(B, P, 16, dtype=torch.float32, device=position.device)
         parts[:, :, :9] = pose_to_camera[:, :, :3, :3].reshape(B, P, 9)
         parts[:, :, 9:12] = pose_to_camera[:, :, :3, 3]
         parts[:, :, 12] = (self.canonical_bone_length[:, None] / model_input["bone_length"] / self.coordinate_scale)[:, :, 0]
-        pack = self._mlp_pack(model_input["z_rend"])
+        mult_w = bool(self.config.multiply_density_with_triplane_wieght)
+        z_rend = model_input["z_rend"]
+        tri_graph = self._tri_plane_graph(model_input)
+        params = self.mlp.as_dict()
+        if torch.is_grad_enabled() and (tri_graph.requires_grad or z_rend.requires_grad or
+                                        any(p.requires_grad for p in params.values())):
+            if mult_w:
+                raise NotImplementedError("backward with multiply_density_with_triplane_wieght is not implemented")
+            k = dict(points=position.detach(), parts=parts, canonical_pose=self.canonical_pose, mlp_mode=self.mlp_mode,
+                     pack_fn=self._mlp_pack_from)
+            flat = [params[f"layers.{i}.{leaf}"] for i in range(3) for leaf in _MLP_LEAVES]
+            return _QueryFunction.apply(k, tri_graph, z_rend, *flat)
+        tri, feat_cl = self._tri_plane_pair(model_input)
+        pack = self._mlp_pack(z_rend)
         den, col, vb = ops.query_fwd(position, parts, self.canonical_pose, tri, feat_cl, pack, mlp_mode=self.mlp_mode,
-                                     multiply_density_with_weight=bool(self.config.multiply_density_with_triplane_wieght),
-                                     need_valid=True)
+                                     multiply_density_with_weight=mult_w, need_valid=True)
         if not self.training:
             self.temporal_state["valid_bits"] = vb
         return den, col
+
+
+_MLP_LEAVES = ("conv.weight", "conv.modulation.weight", "conv.modulation.bias", "bias")
+
+
+class _QueryFunction(torch.autograd.Function):
+    """Differentiable point query: forward = enarf_prepare (MLP pack) + enarf_triplane_pack + enarf_query_fwd, backward =
+    enarf_query_bwd + enarf_weight_grad + enarf_prepare_bwd + un-pack. Differentiable inputs: the tri-plane, z_rend and
+    the 12 StyledMLP tensors."""
+
+    @staticmethod
+    def forward(ctx, k, tri, z_rend, *params):
+        mlp = {f"layers.{i}.{leaf}": params[4 * i + j] for i in range(3) for j, leaf in enumerate(_MLP_LEAVES)}
+        tri_c = tri.detach().contiguous()
+        feat_cl = ops.triplane_pack(tri_c)
+        pack = k["pack_fn"](z_rend.detach(), {n: t.detach() for n, t in mlp.items()})
+        den, col = ops.query_fwd(k["points"], k["parts"], k["canonical_pose"], tri_c, feat_cl, pack, mlp_mode=k["mlp_mode"])
+        ctx.k = k
+        ctx.save_for_backward(tri_c, feat_cl, pack, z_rend.detach(), *[p.detach() for p in params])
+        return den, col
+
+    @staticmethod
+    def backward(ctx, g_den, g_col):
+        k = ctx.k
+        tri_c, feat_cl, pack, z_rend = ctx.saved_tensors[:4]
+        params = ctx.saved_tensors[4:]
+        mlp = {f"layers.{i}.{leaf}": params[4 * i + j] for i in range(3) for j, leaf in enumerate(_MLP_LEAVES)}
+        grad_tri, dW, db = ops.query_bwd(k["points"], k["parts"], k["canonical_pose"], tri_c, feat_cl, pack, g_den, g_col)
+        pg, dz = ops.prepare_bwd(z_rend, mlp, dW)
+        grads = []
+        for i in range(3):
+            grads += [pg[f"layers.{i}.conv.weight"], pg[f"layers.{i}.conv.modulation.weight"],
+                      pg[f"layers.{i}.conv.modulation.bias"], db[i].reshape(params[4 * i + 3].shape)]
+        return (None, grad_tri, dz) + tuple(grads)
 
 
 def ops_prepare_mlp_only(model: TriPlaneNARF, z_rend: torch.Tensor, sd: Optional[Dict[str, torch.Tensor]] = None):

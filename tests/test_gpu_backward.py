@@ -149,3 +149,30 @@ def test_query_backward_matches_oracle_autograd(B, style_dim, N):
     only_c = ops.query_bwd(pts.cuda(), ds.parts, ds.cpose, ds.tri, ds.feat_cl, ds.pack, None, gC.cuda())
     only_d = ops.query_bwd(pts.cuda(), ds.parts, ds.cpose, ds.tri, ds.feat_cl, ds.pack, gD.cuda(), None)
     assert_close((only_c[0] + only_d[0]).cpu(), o_tri, "linearity in the output gradients", 1e-3)
+
+
+def test_model_query_entry_point_is_differentiable():
+    """calc_density_and_color_from_camera_coord_v2 of the mirror model under autograd (enarf_query_bwd behind it): the
+    tri-plane parameter and z_rend receive the oracle's gradients."""
+    from test_gpu_api import _model
+    sc = Scene(32, 1, "center_fixed", 20)
+    m = _model(sc, Nc=48, Nf=32, style_dim=20, mlp_mode="f32").train()
+    s = sc.raw
+    g = torch.Generator().manual_seed(2)
+    jp = sc.pose_scaled[:, :, :3, 3]
+    pick = torch.randint(0, jp.shape[1], (1, 500), generator=g)
+    pts = (torch.gather(jp, 1, pick[..., None].expand(-1, -1, 3)).permute(0, 2, 1) + 0.2 * torch.randn(1, 3, 500, generator=g)).contiguous()
+    gD, gC = torch.randn(1, 1, 500, generator=g), torch.randn(1, 3, 500, generator=g)
+    z = s["z_rend"].cuda().requires_grad_(True)
+    mi = {"z": None, "z_rend": z, "bone_length": sc.bl_parts.cuda(), "truncation_psi": 1}
+    den, col = m.calc_density_and_color_from_camera_coord_v2(pts.cuda(), sc.pose_scaled.cuda(), None, mi)
+    ((den * gD.cuda()).sum() + (col * gC.cuda()).sum()).backward()
+    tri = s["tri_plane"].clone().requires_grad_(True)
+    mlp = {k: v.clone().requires_grad_(True) for k, v in s["mlp"].items() if "noise" not in k}
+    zc = s["z_rend"].clone().requires_grad_(True)
+    oden, ocol, _ = O.query(pts, sc.pose_scaled, sc.scale, sc.cpose, tri, O.modulated_weights(mlp, zc))
+    assert_close(den.detach().cpu(), oden.detach(), "density")
+    o_tri, o_z, o_b = torch.autograd.grad((oden * gD).sum() + (ocol * gC).sum(), [tri, zc, mlp["layers.2.bias"]])
+    assert_close(m.tri_plane.grad.cpu(), o_tri, "tri_plane.grad", 1e-3)
+    assert_close(z.grad.cpu(), o_z, "z_rend.grad", 1e-3)
+    assert_close(m.mlp.layers[2].bias.grad.cpu(), o_b, "layers.2.bias.grad", 1e-3)
