@@ -1,0 +1,76 @@
+"""Density sweep behind `create_mesh` (libraries/NARF/mesh_rendering.py:50-81 of the reference).
+
+The reference builds the (2/voxel_size + 1)^3 grid on the host, pushes it through
+`calc_density_and_color_from_camera_coord_v2` in `render_bs` chunks and hands the volume to `mcubes`. Here the grid is
+generated on the device, chunk by chunk, and queried with `enarf_query_fwd` (density only); the volume stays on the
+device. Marching cubes (`mcubes`) and the rasteriser (`pytorch3d`) are third-party and not part of this package:
+`create_mesh` raises ImportError where the reference would, after the volume is available from `density_volume`.
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+import torch
+
+from ... import ops
+
+
+def _grid_chunk(D: int, start: int, stop: int, center: torch.Tensor, scale: float, dev: torch.device) -> torch.Tensor:
+    """Points [start, stop) of stack(meshgrid(bins, bins, bins)).reshape(1, 3, -1), bins = arange(-c, c + 1) / c."""
+    c = (D - 1) // 2
+    idx = torch.arange(start, stop, device=dev, dtype=torch.int64)
+    ix = torch.div(idx, D * D, rounding_mode="floor")
+    iy = torch.div(idx, D, rounding_mode="floor") % D
+    iz = idx % D
+    p = torch.stack([ix, iy, iz], dim=0).to(torch.float32)
+    p = (p - c) / c                                           # == torch.arange(-c, c + 1) / c, elementwise
+    return ((p[None] + center.to(dev).reshape(1, 3, 1)) * scale).contiguous()
+
+
+@torch.no_grad()
+def density_volume(model, pose_to_camera: torch.Tensor, center: torch.Tensor, voxel_size: float = 0.003,
+                   model_input: Dict = {}, chunk: int = 1 << 23) -> torch.Tensor:
+    """(D, D, D) density grid, D = 2 * int(1 / voxel_size) + 1, exactly the tensor the reference feeds to marching
+    cubes. pose_to_camera (1, P, 4, 4): part frames with UNSCALED translation (scaled here, on a copy - the reference
+    scales its argument in place)."""
+    cube = int(1 / voxel_size)
+    D = 2 * cube + 1
+    dev = pose_to_camera.device
+    pose = pose_to_camera.clone()
+    if model.coordinate_scale != 1:
+        pose[:, :, :3, 3] *= model.coordinate_scale
+    B, P = pose.shape[:2]
+    assert B == 1, "create_mesh sweeps one pose"
+    parts = torch.zeros(B, P, 16, dtype=torch.float32, device=dev)
+    parts[:, :, :9] = pose[:, :, :3, :3].reshape(B, P, 9)
+    parts[:, :, 9:12] = pose[:, :, :3, 3]
+    parts[:, :, 12] = (model.canonical_bone_length[:, None] / model_input["bone_length"] / model.coordinate_scale)[:, :, 0]
+    tri, feat_cl = model._tri_plane_pair(model_input)
+    pack = model._mlp_pack(model_input["z_rend"])
+    mult_w = bool(model.config.multiply_density_with_triplane_wieght)
+    total = D * D * D
+    out = torch.empty(total, dtype=torch.float32, device=dev)
+    for s in range(0, total, chunk):
+        e = min(s + chunk, total)
+        pts = _grid_chunk(D, s, e, center, float(model.coordinate_scale), dev)
+        den, _ = ops.query_fwd(pts, parts, model.canonical_pose, tri, feat_cl, pack, mlp_mode=model.mlp_mode,
+                               multiply_density_with_weight=mult_w, need_color=False)
+        out[s:e] = den.reshape(-1)
+    return out.reshape(D, D, D)
+
+
+def create_mesh(model, pose_to_camera, center, voxel_size=0.003, mesh_th=15, model_input={}):
+    """mesh_rendering.py:50-81: density sweep + marching cubes -> (vertices, triangles, textures)."""
+    density = density_volume(model, pose_to_camera, center, voxel_size, model_input)
+    try:
+        import mcubes
+        from pytorch3d.renderer import Textures
+    except ImportError as e:      # same third-party requirements as the reference
+        raise ImportError("create_mesh needs PyMCubes and pytorch3d (as the reference does); the density grid itself "
+                          "is available from density_volume()") from e
+    cube = int(1 / voxel_size)
+    dev = pose_to_camera.device
+    vertices, triangles = mcubes.marching_cubes(density.cpu().numpy(), mesh_th)
+    vertices = torch.tensor((vertices - cube) * voxel_size, device=dev).float() + center[:, :, 0]
+    triangles = torch.tensor(triangles.astype("int64")).to(dev)
+    return vertices, triangles, Textures(verts_rgb=torch.ones_like(vertices)[None])
