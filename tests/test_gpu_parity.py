@@ -461,3 +461,20 @@ def test_render_edge_cases_no_hit_single_ray_minimal_samples(ops):
     assert_close(_cpu(o2.color), rc, "half-empty batch colour")
     assert_close(_cpu(o2.mask), rm, "half-empty batch mask")
     assert int(_cpu(o2.counters)[2]) == 2 * 130 and float(_cpu(o2.mask)[1].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("Nc,Nf", [(64, 64), (128, 128), (33, 17), (100, 70), (16, 128)])
+def test_render_sample_count_variants_vs_oracle(ops, Nc, Nf):
+    """Sample counts that change the tile / spare-wave layout of the march: four full coarse tiles (no spare wave),
+    two samples per lane, counts that are not multiples of 16 - a band of consecutive rays against the oracle."""
+    sc = Scene(32, 1, "center_fixed", 20)
+    ds = DeviceScene(sc)
+    coord = sc.raw["image_coord"][..., 32 * 12:32 * 12 + 96].contiguous()
+    g = torch.Generator().manual_seed(Nc * 131 + Nf)
+    bins = torch.rand(1, 96, Nf, generator=g).sort(-1).values
+    out = ds.render(coord, Nc, Nf, bins)
+    rc, rm, rd = sc.oracle_render(coord, Nc, Nf, bins, taps=False)
+    assert float(rm.max()) > 0.1
+    assert_close(_cpu(out.color), rc, f"colour Nc={Nc} Nf={Nf}")
+    assert_close(_cpu(out.mask), rm, f"mask Nc={Nc} Nf={Nf}")
+    assert_close(_cpu(out.disparity), rd, f"disparity Nc={Nc} Nf={Nf}")
