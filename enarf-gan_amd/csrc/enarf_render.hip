@@ -617,6 +617,26 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
                 if (active && (lane & 3) == 0) { l_cbits[i] = bits; l_cwmax[i] = wmax; }
             }
         }
+        // the sorted uniforms of the importance draw do not depend on the coarse pass: the wave that will run S2 draws
+        // them now, while the others are still in their coarse tiles (u_(i) = E_1+..+E_i / E_1+..+E_{Nf+1})
+        float usort[SPL];
+#pragma unroll
+        for (int s = 0; s < SPL; ++s) usort[s] = 0.0f;
+        if (wave == spare_wave && !a.bins && !(ablate & 8)) {
+            float esum[SPL];
+            uint32_t r1_first = 0;
+#pragma unroll
+            for (int s = 0; s < SPL; ++s) {
+                uint32_t rnd[4];
+                philox4x32(rid, 0u, (uint32_t)(64 * s + lane), 0x454E4152u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), rnd);
+                esum[s] = (64 * s + lane < Nf) ? -__logf(1.0f - u32_to_unit(rnd[0])) : 0.0f;
+                if (s == 0) r1_first = rnd[1];
+            }
+            wv_scan_incl<SPL>(esum, lane);
+            const float etot = __shfl(esum[SPL - 1], 63) - __logf(1.0f - u32_to_unit((uint32_t)__shfl((int)r1_first, 0)));
+#pragma unroll
+            for (int s = 0; s < SPL; ++s) usort[s] = fminf(esum[s] / etot, 0.99999994f);
+        }
         TMR(S, 4);
         TMR4(S, 7);
         __syncthreads();
@@ -673,23 +693,15 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
                 // Sorted uniforms come directly from exponential spacings (u_(i) = E_1+..+E_i / E_1+..+E_{Nf+1}),
                 // each is pushed through the inverse CDF (monotone, so the bins come out sorted): bin index by
                 // binary search, position inside the bin by the leftover - the same law as multinomial + U/Nc.
-                float cdf[SPL], esum[SPL];
-                uint32_t r1_first = 0;
+                // (the sorted uniforms were drawn before the barrier)
+                float cdf[SPL];
 #pragma unroll
-                for (int s = 0; s < SPL; ++s) {
-                    cdf[s] = ws[s];
-                    uint32_t rnd[4];
-                    philox4x32(rid, 0u, (uint32_t)(64 * s + lane), 0x454E4152u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), rnd);
-                    esum[s] = (64 * s + lane < Nf) ? -__logf(1.0f - u32_to_unit(rnd[0])) : 0.0f;
-                    if (s == 0) r1_first = rnd[1];
-                }
+                for (int s = 0; s < SPL; ++s) cdf[s] = ws[s];
                 wv_scan_incl<SPL>(cdf, lane);
-                wv_scan_incl<SPL>(esum, lane);
                 const float total = wv_get<SPL>(cdf, Nc - 1);
-                const float etot = __shfl(esum[SPL - 1], 63) - __logf(1.0f - u32_to_unit((uint32_t)__shfl((int)r1_first, 0)));
 #pragma unroll
                 for (int s = 0; s < SPL; ++s) {
-                    const float target = fminf(esum[s] / etot, 0.99999994f) * total;
+                    const float target = usort[s] * total;
                     int lo = 0, hi = Nc - 1;   // smallest i with cdf[i] > target
 #pragma unroll
                     for (int it = 0; it < 5 + SPL; ++it) {
