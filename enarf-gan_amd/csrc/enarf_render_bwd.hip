@@ -90,6 +90,33 @@ __device__ __forceinline__ void scatter_plane(float *__restrict__ gpl, float *ti
 }
 
 
+// One scalar contribution per lane into the part-probability gradient planes. Consecutive quads (= consecutive samples
+// of the ray) mostly hit the same texel of the same part, so lanes with the same plane index g first add up along the
+// row of four quads (segmented scan by DPP row shifts of 4 and 8 lanes over runs of equal element index) and only the
+// last lane of each run issues the atomic. EVERY lane of the wave must call this (DPP reads neighbours' registers).
+__device__ __forceinline__ int dpp_i(int old, int v, int ctrl_sel) {
+    return ctrl_sel == 0 ? __builtin_amdgcn_update_dpp(old, v, 0x114, 0xF, 0xF, false)      // row_shr:4
+         : ctrl_sel == 1 ? __builtin_amdgcn_update_dpp(old, v, 0x118, 0xF, 0xF, false)      // row_shr:8
+                         : __builtin_amdgcn_update_dpp(old, v, 0x104, 0xF, 0xF, false);     // row_shl:4
+}
+__device__ __forceinline__ void mask_tap_add(float *__restrict__ gmask, bool on, int elem, float v, int lane) {
+    const int key = on ? elem : -2 - lane;                        // inactive lanes never match a neighbour
+    float acc = on ? v : 0.0f;
+    int head = (dpp_i(-1, key, 0) != key) ? 1 : 0;                // run starts here (also at the start of a row)
+    {
+        const float pv = __builtin_bit_cast(float, dpp_i(0, __builtin_bit_cast(int, acc), 0));
+        const int ph = dpp_i(1, head, 0);
+        if (!head) { acc += pv; head |= ph; }
+    }
+    {
+        const float pv = __builtin_bit_cast(float, dpp_i(0, __builtin_bit_cast(int, acc), 1));
+        const int ph = dpp_i(1, head, 1);
+        if (!head) { acc += pv; head |= ph; }
+    }
+    const bool tail = dpp_i(-1, key, 2) != key;                   // the next quad starts another run (or the row ends)
+    if (on && tail) atomicAdd(gmask + elem, acc);
+}
+
 // what the per-tile stages of the backward need besides the query context (shared by the ray and the point kernels)
 struct BwdTile {
     int H, W;
@@ -233,13 +260,14 @@ __device__ __forceinline__ void bwd_backward_tile(const QueryCtx &S, const BwdTi
         }
         dot += quad_perm_f<0xB1>(dot);
         dot += quad_perm_f<0x4E>(dot);                                  // d loss / d w_k, quad-uniform
-        if (act && g4 < 3 && !(ENARF_BWD_ABLATE & 2)) {   // w = s0 s1 s2, s = sigmoid(m): dw/dm_g = w (1 - s_g)
-            const float gm = dot * wk * (1.0f - sg);
-            float *gp = T.gmask + (size_t)(3 * k + g4) * T.mplane;
-            if (t.w00 != 0.0f) atomicAdd(gp + t.o00, t.w00 * gm);
-            if (t.w01 != 0.0f) atomicAdd(gp + t.o01, t.w01 * gm);
-            if (t.w10 != 0.0f) atomicAdd(gp + t.o10, t.w10 * gm);
-            if (t.w11 != 0.0f) atomicAdd(gp + t.o11, t.w11 * gm);
+        {   // w = s0 s1 s2, s = sigmoid(m): dw/dm_g = w (1 - s_g); lane g adds into the four taps of its plane
+            const bool mon = act && g4 < 3 && !(ENARF_BWD_ABLATE & 2);
+            const float gm = mon ? dot * wk * (1.0f - sg) : 0.0f;
+            const int pbase = (3 * k + g4) * (int)T.mplane;
+            mask_tap_add(T.gmask, mon && t.w00 != 0.0f, pbase + t.o00, t.w00 * gm, lane);
+            mask_tap_add(T.gmask, mon && t.w01 != 0.0f, pbase + t.o01, t.w01 * gm, lane);
+            mask_tap_add(T.gmask, mon && t.w10 != 0.0f, pbase + t.o10, t.w10 * gm, lane);
+            mask_tap_add(T.gmask, mon && t.w11 != 0.0f, pbase + t.o11, t.w11 * gm, lane);
         }
         // every lane takes part (wave-uniform): inactive quads contribute empty rows
         scatter_plane(T.gfeat, T.ttile, t0, wk, act, dxg, lane);
