@@ -92,20 +92,13 @@ __host__ __device__ inline size_t ws_total_bytes(int B, int n) {
 // cost class of a live ray from the number of candidate parts on its marched segment (which tracks the ray's gather
 // rounds closely: correlation 0.98 on the bench frame): 0 = heaviest
 __device__ __forceinline__ int ray_cost_class(uint32_t cand) {
-#ifndef ENARF_COST_CLASSES
-#define ENARF_COST_CLASSES 1
-#endif
     const int pc = __popc(cand);
-#if ENARF_COST_CLASSES == 1 && ENARF_NUM_CLASSES == 8
+#if ENARF_NUM_CLASSES == 8        // measured: 4 % slower than 4 classes; 2 classes are on par with 4
     return pc >= 12 ? 0 : pc >= 10 ? 1 : pc >= 8 ? 2 : pc >= 6 ? 3 : pc >= 4 ? 4 : pc == 3 ? 5 : pc == 2 ? 6 : 7;
-#elif ENARF_COST_CLASSES == 1 && ENARF_NUM_CLASSES == 2
+#elif ENARF_NUM_CLASSES == 2
     return pc >= 6 ? 0 : 1;
-#elif ENARF_COST_CLASSES == 1
-    return pc >= 10 ? 0 : pc >= 6 ? 1 : pc >= 3 ? 2 : 3;
-#elif ENARF_COST_CLASSES == 2      // experiment: lightest first
-    return pc >= 10 ? 3 : pc >= 6 ? 2 : pc >= 3 ? 1 : 0;
 #else
-    return 0;
+    return pc >= 10 ? 0 : pc >= 6 ? 1 : pc >= 3 ? 2 : 3;
 #endif
 }
 
@@ -152,11 +145,7 @@ struct RayQueue {
         lists = reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(workspace) + ws_list_off((long long)B * n));
         l_q = lds_ints;
         band = ws_band_size(B, n);
-#ifdef ENARF_NO_HOME_BAND
-        home = (int)(blockIdx.x & (kQueues - 1));
-#else
         home = xcc_id() & (kQueues - 1);
-#endif
         if (tid < kQueues * kClasses) l_q[kQCountsOff + tid] = (int)wsh[kWsCountsOff + tid];
         if (tid == 0) { l_q[kQCursorOff] = home; l_q[kQCursorOff + 1] = 0; l_q[kQCursorOff + 2] = 0; }
         __syncthreads();
