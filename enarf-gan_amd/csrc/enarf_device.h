@@ -218,10 +218,12 @@ __device__ __forceinline__ Taps make_taps(float x, float y, int H, int W) {
     const int cx0 = min(max(x0, 0), W - 1), cx1 = min(max(x1, 0), W - 1);
     const int cy0 = min(max(y0, 0), H - 1), cy1 = min(max(y1, 0), H - 1);
     t.o00 = cy0 * W + cx0; t.o01 = cy0 * W + cx1; t.o10 = cy1 * W + cx0; t.o11 = cy1 * W + cx1;
-    t.w00 = (bx0 & by0) ? ax0 * ay0 : 0.0f;
-    t.w01 = (bx1 & by0) ? ax1 * ay0 : 0.0f;
-    t.w10 = (bx0 & by1) ? ax0 * ay1 : 0.0f;
-    t.w11 = (bx1 & by1) ? ax1 * ay1 : 0.0f;
+    // out-of-bounds taps weigh zero: zero the axis factor (all factors are >= 0, so the products are the same bits)
+    const float zx0 = bx0 ? ax0 : 0.0f, zx1 = bx1 ? ax1 : 0.0f, zy0 = by0 ? ay0 : 0.0f, zy1 = by1 ? ay1 : 0.0f;
+    t.w00 = zx0 * zy0;
+    t.w01 = zx1 * zy0;
+    t.w10 = zx0 * zy1;
+    t.w11 = zx1 * zy1;
     return t;
 }
 __device__ __forceinline__ float sample_scalar_plane(const float *__restrict__ plane, float x, float y,
@@ -233,7 +235,9 @@ __device__ __forceinline__ float sample_scalar_plane(const float *__restrict__ p
     acc += plane[t.o11] * t.w11;
     return acc;
 }
-__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
+// sigmoid from the hardware exp2 and reciprocal (v_exp_f32, v_rcp_f32: ~1 ulp each; the part probabilities feed a 1e-4
+// comparison, not a bit-exact one). exp2 overflows to +inf for v < -88: 1 / inf = 0, the right limit.
+__device__ __forceinline__ float sigmoidf_(float v) { return __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
 // StyledConv activation: LeakyReLU(0.2) * sqrt(2)   (libraries/custom_stylegan2/net.py:318)
 __device__ __forceinline__ float styled_act(float v) {
