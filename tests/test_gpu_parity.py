@@ -478,3 +478,25 @@ def test_render_sample_count_variants_vs_oracle(ops, Nc, Nf):
     assert_close(_cpu(out.color), rc, f"colour Nc={Nc} Nf={Nf}")
     assert_close(_cpu(out.mask), rm, f"mask Nc={Nc} Nf={Nf}")
     assert_close(_cpu(out.disparity), rd, f"disparity Nc={Nc} Nf={Nf}")
+
+
+def test_steps_on_two_streams_do_not_interfere(ops):
+    """Steps issued on two HIP streams with private intermediates (bench.py --streams 2) give the same bits as serial
+    steps: the workspace is per stream, everything else is read-only."""
+    g, sc, coord, bins = _render_case("render_c1_128_b1_p23")
+    ds = DeviceScene(sc)
+    s, d = sc.raw, ds.dev
+    full = s["image_coord"].to(d)
+    ref = ds.render(full, 48, 64, None, seed=11)
+    streams = [torch.cuda.Stream(d), torch.cuda.Stream(d)]
+    torch.cuda.synchronize()
+    outs = []
+    for i in range(6):
+        with torch.cuda.stream(streams[i % 2]):
+            feat = torch.empty_like(ds.feat_cl)
+            st = ops.RenderStep(s["pose_to_camera"].to(d), s["bone_length"].to(d), sc.cbl.to(d), s["z_rend"].to(d), ds.mlp,
+                                s["parents"], sc.ol, sc.cs, full, ds.inv_K, ds.cpose, ds.tri, feat, 48, 64, seed=11)
+            outs.append(st.run())
+    torch.cuda.synchronize()
+    for o in outs:
+        assert torch.equal(o.color, ref.color) and torch.equal(o.mask, ref.mask)
