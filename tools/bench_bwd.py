@@ -17,6 +17,9 @@ sc = synth.make_scene(S, B, "center_fixed", 20, shared_triplane=True)
 cpose, cbl = O.register_canonical_pose(sc["canonical_pose"], sc["parents"], "center_fixed")
 d = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in sc.items()}
 tri = sc["tri_plane"][:1].contiguous().to(dev)
+if os.environ.get("DISTINCT") and B > 1:      # GAN style: one tri-plane per frame
+    g = torch.Generator(device=dev).manual_seed(5)
+    tri = (tri + 0.05 * torch.randn(B, *tri.shape[1:], device=dev, generator=g)).contiguous()
 mlp = {k: v.to(dev) for k, v in sc["mlp"].items()}
 n = S * S
 coord = d["image_coord"].reshape(B, 3, n).contiguous()
