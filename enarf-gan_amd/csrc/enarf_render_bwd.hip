@@ -29,12 +29,13 @@ constexpr int SB_FH = 128;        // head [4][64]
 constexpr int SB_FBITS = 384;     // bits [64]
 constexpr int SB_DZ3 = 448;       // dL/dz3 [4][64]
 constexpr int SB_QUEUE = 704;     // 2 ray ids
-static_assert(SB_QUEUE + kQueueLdsInts <= kScratchFloats, "scratch overflow");
+constexpr int kBwdScratchFloats = 768;
+static_assert(SB_QUEUE + kQueueLdsInts <= kBwdScratchFloats, "scratch overflow");
 
 constexpr int kTRow = 33;                       // floats per texel row of the transpose tile (32 + 1 pad)
-constexpr int kTTile = 16 * kTRow + 16;          // 16 texel rows + 16 texel offsets (ints)
+constexpr int kTTile = 2 * 16 * kTRow + 32;      // two taps x (16 texel rows) + 2 x 16 texel offsets (ints)
 __host__ __device__ inline int bwd_lds_floats(int P) {
-    return PK_B1 + 144 + PKT_FLOATS + P * kLdsPartStride + P * kLdsCanonStride + kScratchFloats + 4 * kTTile;
+    return PK_B1 + 144 + PKT_FLOATS + P * kLdsPartStride + P * kLdsCanonStride + kBwdScratchFloats + 4 * kTTile;
 }
 
 // d loss / d one tap (texel) of every quad of the wave: grad[texel][c] += bilinear weight * w_k * dx[c].
@@ -42,29 +43,32 @@ __host__ __device__ inline int bwd_lds_floats(int P) {
 // wave-instruction covers whole 128-B lines (MI355X_MICROARCH.md, Global float atomics: 64 scattered dwords are
 // ~17x slower), so the 16 x 32 values go through a per-wave LDS tile and come back as lane = (texel pair, channel):
 // 8 atomic instructions, each adding into two contiguous 128-B texel lines.
-__device__ __forceinline__ void scatter_tap(float *__restrict__ gpl, float *tile, int off, float cf, bool on,
-                                            const float dxg[8], int lane) {
+// TWO taps at a time: the quads' rows of tap A and tap B go to the two halves of the tile; half-wave 0 then walks the 16
+// quads of tap A and half-wave 1 those of tap B (lane = channel), merging runs of consecutive quads (= consecutive samples
+// along the ray, which mostly fall on the same texels: the importance samples cluster at the surface) that target the
+// same texel into ONE atomic.
+__device__ __forceinline__ void scatter_tap2(float *__restrict__ gpl, float *tile, int offA, float cfA, int offB, float cfB,
+                                             bool on, const float dxg[8], int lane) {
     const int q = lane >> 2, g = lane & 3;
-    int *toff = reinterpret_cast<int *>(tile + 16 * kTRow);
-    const bool live = on && cf != 0.0f;
-    f32x4 *row = reinterpret_cast<f32x4 *>(tile + q * kTRow + 8 * g);      // 33-float rows: not 16-B aligned -> b32 stores
-    float *rowf = tile + q * kTRow + 8 * g;
-    (void)row;
+    int *toff = reinterpret_cast<int *>(tile + 2 * 16 * kTRow);
+    const bool liveA = on && cfA != 0.0f, liveB = on && cfB != 0.0f;
+    float *rowA = tile + q * kTRow + 8 * g, *rowB = rowA + 16 * kTRow;      // 33-float rows: b32 stores
 #pragma unroll
-    for (int c = 0; c < 8; ++c) rowf[c] = live ? cf * dxg[c] : 0.0f;
-    if (g == 0) toff[q] = live ? off : -1;
+    for (int c = 0; c < 8; ++c) {
+        rowA[c] = liveA ? cfA * dxg[c] : 0.0f;
+        rowB[c] = liveB ? cfB * dxg[c] : 0.0f;
+    }
+    if (g == 0) { toff[q] = liveA ? offA : -1; toff[16 + q] = liveB ? offB : -1; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // each half-wave walks 8 consecutive quads (= consecutive samples along the ray, which mostly fall on the same
-    // texels: the importance samples cluster at the surface) and merges runs that target the same texel into ONE atomic
     {
-        const int ch = lane & 31, h8 = (lane >> 5) * 8;
+        const int ch = lane & 31, h16 = (lane >> 5) * 16;
         int run_o = -1;
         float run_v = 0.0f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int tq = h8 + i;
+        for (int i = 0; i < 16; ++i) {
+            const int tq = h16 + i;
             const int o = toff[tq];
             const float v = tile[tq * kTRow + ch];
             if (o == run_o) {
@@ -83,10 +87,8 @@ __device__ __forceinline__ void scatter_tap(float *__restrict__ gpl, float *tile
 }
 __device__ __forceinline__ void scatter_plane(float *__restrict__ gpl, float *tile, const Taps &t, float wk, bool on,
                                               const float dxg[8], int lane) {
-    scatter_tap(gpl, tile, t.o00, t.w00 * wk, on, dxg, lane);
-    scatter_tap(gpl, tile, t.o01, t.w01 * wk, on, dxg, lane);
-    scatter_tap(gpl, tile, t.o10, t.w10 * wk, on, dxg, lane);
-    scatter_tap(gpl, tile, t.o11, t.w11 * wk, on, dxg, lane);
+    scatter_tap2(gpl, tile, t.o00, t.w00 * wk, t.o01, t.w01 * wk, on, dxg, lane);
+    scatter_tap2(gpl, tile, t.o10, t.w10 * wk, t.o11, t.w11 * wk, on, dxg, lane);
 }
 
 
@@ -314,7 +316,7 @@ __global__ __launch_bounds__(256, kBwdWavesPerSimd) void render_bwd_kernel(const
     S.H = a.H; S.W = a.W; S.P = P; S.mult_w = 0; S.ablate = 0;
     int *l_cand = reinterpret_cast<int *>(scratch + SB_CAND) + wave * 32;
     float *l_fh = scratch + SB_FH, *l_dz3 = scratch + SB_DZ3;
-    float *ttile = scratch + kScratchFloats + wave * kTTile;     // this wave's atomic-transpose tile
+    float *ttile = scratch + kBwdScratchFloats + wave * kTTile;     // this wave's atomic-transpose tile
     uint32_t *l_fbits = reinterpret_cast<uint32_t *>(scratch + SB_FBITS);
     const int Tf = (Nf + 3) >> 2;
     const int j4 = lane >> 2, g4 = lane & 3;
@@ -451,7 +453,7 @@ __global__ __launch_bounds__(256, kBwdWavesPerSimd) void query_bwd_kernel(const 
     T.rows_x = a.rows_x; T.rows_h1 = a.rows_h1; T.rows_h2 = a.rows_h2;
     T.rows_dz1 = a.rows_dz1; T.rows_dz2 = a.rows_dz2; T.rows_dz3 = a.rows_dz3;
     T.rows_per_image = a.rows_per_image; T.row_blocks = a.row_blocks;
-    T.ttile = scratch + kScratchFloats + wave * kTTile;
+    T.ttile = scratch + kBwdScratchFloats + wave * kTTile;
     T.gfeat = a.grad_feat_cl + (size_t)b * a.grad_feat_batch_stride;
     T.gmask = a.grad_mask_planes + (size_t)b * a.grad_mask_batch_stride;
     bwd_stage_image(a.mlp_pack, a.parts, a.canonical_pose, b, P, l_w, l_bias, l_wt, l_parts, l_canon, tid);
