@@ -51,6 +51,10 @@ def parse():
                          "channel-last planes, workspace). With 2, the pre-march launch of step i+1 fills the CUs that the "
                          "persistent march of step i frees in its tail (+7 %% rays/s), but event-bracketed kernel times then "
                          "include the overlap, so the default - and the roofline figure - is strictly serial steps")
+    ap.add_argument("--shard-frame", action="store_true",
+                    help="N > 1: strong scaling of ONE frame batch - every rank marches its contiguous share of the rays "
+                         "(sharding.rays_for_rank) and the 5 floats per ray are all-gathered on every rank each step "
+                         "(SURVEY.md 8e, single DSO frame); default is weak scaling, one frame batch per rank")
     ap.add_argument("--unfused", action="store_true",
                     help="issue prepare / re-layout / render as the three separate C-ABI calls (4 launches + memset) "
                          "instead of enarf_render_step_fwd (2 launches + memset)")
@@ -112,8 +116,10 @@ def main():
     from oracle import enarf_oracle as O   # only for the canonical-pose buffers of the synthetic scene and the cpu_baseline leg
 
     S, B, Nc, Nf = args.size, args.batch, args.nc, args.nf
-    sc = synth.make_scene(S, B, args.origin, args.style_dim, pose_seed=1234 + 100 * rank, shared_triplane=True)
-    n = S * S
+    shard = args.shard_frame and world > 1
+    sc = synth.make_scene(S, B, args.origin, args.style_dim, pose_seed=1234 + (0 if shard else 100 * rank), shared_triplane=True)
+    n_frame = S * S
+    n = n_frame
     P = sc["num_parts"]
     cpose, cbl = O.register_canonical_pose(sc["canonical_pose"], sc["parents"], args.origin)
     d = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in sc.items()}
@@ -124,6 +130,18 @@ def main():
     mlp = {k: v.to(dev) for k, v in sc["mlp"].items()}
     cpose_d, cbl_d = cpose.to(dev), cbl.to(dev)
     coord = d["image_coord"].reshape(B, 3, n).contiguous()
+    if shard:                                   # this rank's contiguous range of every frame's rays
+        from enarf_gan_amd import sharding
+        coord = coord[..., sharding.rays_for_rank(n_frame, rank, world)].contiguous()
+        n = coord.shape[-1]
+
+    def gather_outputs(o):
+        """all ranks end up with the whole frame: one collective of 5 floats per ray"""
+        local = torch.cat([o.color, o.mask[:, None], o.disparity[:, None]], dim=1)
+        if dist.get_backend() == "nccl":
+            return sharding.all_gather_rays(local, n_frame)
+        return sharding.all_gather_rays(local.cpu(), n_frame)        # rehearsal backends move host tensors
+
     n_streams = 1 if args.unfused else max(1, args.streams)
     streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(n_streams - 1)]
     sets = []                                      # per-stream intermediates: steps on different streams share only inputs
@@ -143,7 +161,10 @@ def main():
 
     def step(i, count=False):
         if not args.unfused:
-            return bound_step(99 + i, count).run()
+            o = bound_step(99 + i, count).run()
+            if shard:
+                gather_outputs(o)
+            return o
         ops.prepare(d["pose_to_camera"], d["bone_length"], cbl_d, d["z_rend"], mlp, sc["parents"], args.origin,
                     3.0, parts_out=parts, pack_out=pack)
         if not args.cache_triplane:
@@ -162,7 +183,9 @@ def main():
             if args.unfused:
                 step(i)
             else:
-                bound_step(99 + i, k=i % n_streams).run()
+                o = bound_step(99 + i, k=i % n_streams).run()
+                if shard:
+                    gather_outputs(o)
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     torch.cuda.synchronize()
@@ -176,8 +199,10 @@ def main():
                 st = bound_step(99, k=k)
                 st.run(ops.STEP_PRE)
                 ev0[i].record()
-                st.run(ops.STEP_MARCH)
+                o = st.run(ops.STEP_MARCH)
                 ev1[i].record()
+                if shard:
+                    gather_outputs(o)
             continue
         ops.prepare(d["pose_to_camera"], d["bone_length"], cbl_d, d["z_rend"], mlp, sc["parents"], args.origin,
                     3.0, parts_out=parts, pack_out=pack)
@@ -198,7 +223,7 @@ def main():
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
 
     if rank == 0:
-        rays_per_step = world * B * n
+        rays_per_step = B * n_frame if shard else world * B * n
         value = rays_per_step * args.steps / elapsed
         # V*12*(C+1)*4 gathered texel bytes + each tri-plane once + outputs (+ fine side outputs)
         alg_bytes = V * 1584 + tri.shape[0] * (96 + 3 * P) * 256 * 256 * 4 + B * n * 20 + B * n * (2 * Nf - 1) * 4
@@ -214,16 +239,20 @@ def main():
         out = {
             "metric": "rendered rays/sec (128^2, 64 samples/ray, 24 bones)", "value": value, "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if shard else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"C1: DSO-style {S}x{S} frame, Nc {Nc} + Nf {Nf} samples/ray, 24 joints -> P={P} parts "
                                    f"({args.origin}), {B} frame/GPU/step, {'per-frame' if tri.shape[0] > 1 else 'constant'} fp32 tri-plane 256^2x(96+{3 * P}), "
                                    f"in-kernel Philox importance sampling",
+                       "sharding": "rays of one frame batch across ranks + all-gather of outputs" if shard else "one frame batch per rank",
                        "streams": n_streams, "mlp_arith": args.mlp_mode, "early_stop_eps": args.early_stop_eps, "triplane_relayout_in_step": not args.cache_triplane,
                        "step": ("enarf_prepare + enarf_triplane_pack + enarf_render_fwd" if args.unfused else
                                 "enarf_render_step_fwd (pre-march launch: re-layout + prepare + ray set-up; then the march)")},
             "roofline": {"bound": "hbm", "kernel": "enarf::render_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                         # tri-plane once + outputs: what would have to cross HBM with perfect caching
+                         "compulsory_bytes_per_launch": alg_bytes - V * 1584,
+                         "compulsory_GBps": (alg_bytes - V * 1584) / (kern_ms * 1e-3) / 1e9,
                          "valid_part_point_pairs": V, "rays_marched": rays_marched, "mlp_tiles_of_16": tiles,
                          "gather_rounds": rounds, "gather_lane_utilisation": V / max(16 * rounds, 1),
                          "mfma_eligible_tflops": q * 12800 / (kern_ms * 1e-3) / 1e12,
