@@ -60,6 +60,7 @@ class RenderArgs(C.Structure):
         ("dbg_depth_min", _f32p), ("dbg_depth_max", _f32p), ("dbg_ray_valid", _f32p),
         ("dbg_coarse_density", _f32p), ("dbg_fine_density", _f32p), ("dbg_fine_color", _f32p),
         ("dbg_fine_valid", _f32p), ("dbg_bins", _f32p), ("counters", _f32p), ("workspace", _f32p),
+        ("ws_epoch", C.c_int),
     ]
 
 

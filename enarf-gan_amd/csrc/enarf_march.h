@@ -77,8 +77,19 @@ constexpr int kWsCountsOff = 16;                                     // u32 inde
 constexpr int kWsHeadsOff = (kWsCountsOff + kQueues * kClasses + 15) / 16 * 16;   // u32 index of the first queue head
 constexpr int kWsHeadStride = 16;                                    // u32 per queue head slot
 constexpr int kWsHeaderBytes = (kWsHeadsOff + kQueues * kClasses * kWsHeadStride) * 4;
-__host__ __device__ inline size_t ws_records_off() { return kWsHeaderBytes; }
-__host__ __device__ inline size_t ws_list_off(long long total_rays) { return kWsHeaderBytes + (size_t)total_rays * sizeof(RayRec); }
+// TWO headers, so that nobody has to clear one between launches: the launch with epoch k (> 0) uses header k & 1, which
+// the launch with epoch k - 1 cleared while it was using the other one; epoch 0 = the library clears both with a fill
+// first (always safe; what a caller that does not count its calls passes) and uses header 0.
+__host__ __device__ inline size_t ws_header_off(int epoch) { return (epoch > 0 && (epoch & 1)) ? (size_t)kWsHeaderBytes : 0; }
+__host__ __device__ inline size_t ws_other_header_off(int epoch) { return (epoch > 0 && (epoch & 1)) ? 0 : (size_t)kWsHeaderBytes; }
+__host__ __device__ inline size_t ws_records_off() { return 2 * (size_t)kWsHeaderBytes; }
+__host__ __device__ inline size_t ws_list_off(long long total_rays) { return ws_records_off() + (size_t)total_rays * sizeof(RayRec); }
+// any workgroup of the launch that fills header `epoch` (all 256 threads): clear the other header for the next launch
+__device__ __forceinline__ void ws_clear_other_header(void *workspace, int epoch, int tid) {
+    if (epoch <= 0) return;
+    unsigned int *o = reinterpret_cast<unsigned int *>(reinterpret_cast<char *>(workspace) + ws_other_header_off(epoch));
+    for (int i = tid; i < kWsHeaderBytes / 4; i += 256) o[i] = 0u;
+}
 // Bands are cut in the padded ray index b * npad + ray (npad = 64 * set-up blocks per image), in multiples of 64, so
 // that the 64 rays of one set-up block always fall into one band.
 __host__ __device__ inline long long ws_npad(int n) { return 64ll * ((n + 63) / 64); }
@@ -138,8 +149,8 @@ struct RayQueue {
     // every thread; ends with a barrier. The list lengths are final (written by the set-up pass of an earlier launch):
     // staged once, so that a pop never loads from the header (a load from a line that is being hit by atomics from the
     // whole chip takes tens of microseconds).
-    __device__ __forceinline__ void init(void *workspace, int B, int n, int *lds_ints, int tid) {
-        unsigned int *wsh = reinterpret_cast<unsigned int *>(workspace);
+    __device__ __forceinline__ void init(void *workspace, int epoch, int B, int n, int *lds_ints, int tid) {
+        unsigned int *wsh = reinterpret_cast<unsigned int *>(reinterpret_cast<char *>(workspace) + ws_header_off(epoch));
         heads = wsh + kWsHeadsOff;
         recs = reinterpret_cast<const RayRec *>(reinterpret_cast<const char *>(workspace) + ws_records_off());
         lists = reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(workspace) + ws_list_off((long long)B * n));

@@ -436,7 +436,7 @@ __device__ __forceinline__ void ray_setup_block(const enarf_render_args &a, cons
     }
     const long long band = ws_band_size(a.B, n);
     const int q = (int)(((long long)b * ws_npad(n) + 64ll * blk) / band);
-    unsigned int *wsh = reinterpret_cast<unsigned int *>(a.workspace);
+    unsigned int *wsh = reinterpret_cast<unsigned int *>(reinterpret_cast<char *>(a.workspace) + ws_header_off(a.ws_epoch));
     __syncthreads();
     if (tid < kClasses) {
         const int tot = l_cnt[tid] + l_cnt[kClasses + tid] + l_cnt[2 * kClasses + tid] + l_cnt[3 * kClasses + tid];
@@ -458,6 +458,7 @@ __device__ __forceinline__ void ray_setup_block(const enarf_render_args &a, cons
 __global__ __launch_bounds__(256) void ray_setup_kernel(const enarf_render_args a, int blocks_per_image) {
     __shared__ __attribute__((aligned(16))) float smem[kSetupSmemFloats];
     enarf_prepare_args unused;   // never read with RAW = false
+    if (blockIdx.x == 0) ws_clear_other_header(a.workspace, a.ws_epoch, threadIdx.x);
     ray_setup_block<false>(a, unused, blockIdx.x / blocks_per_image, blockIdx.x % blocks_per_image, threadIdx.x, smem);
 }
 
@@ -481,6 +482,7 @@ __global__ __launch_bounds__(256) void pre_march_kernel(const PreParams q) {
     const int tid = threadIdx.x;
     // long-latency roles first (few blocks, serial chains), the bandwidth-bound re-layout blocks fill in behind them
     if (id < q.n_prep) {
+        if (id == 0) ws_clear_other_header(q.rend.workspace, q.rend.ws_epoch, tid);
         prepare_block(q.prep, id % 3, id / 3, tid, smem);
         return;
     }
@@ -527,7 +529,7 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
     QueryCtx S;
     float *scratch = lds + (lds_total_floats<MODE>(P) - kScratchFloats);
     int *l_q = reinterpret_cast<int *>(scratch + SC_QUEUE);
-    rq.init(a.workspace, a.B, n, l_q, tid);
+    rq.init(a.workspace, a.ws_epoch, a.B, n, l_q, tid);
     if (tid == 0) rq.pop(0);
     __syncthreads();
     int cur = rq.get(0);
@@ -952,8 +954,10 @@ extern "C" int enarf_query_fwd(const enarf_query_args *args, enarf_stream_t stre
 namespace enarf {
 // zero the workspace header and run the ray set-up pre-pass (also used by the backward)
 int launch_ray_setup(const enarf_render_args &a, hipStream_t st) {
-    hipError_t e = hipMemsetAsync(a.workspace, 0, kWsHeaderBytes, st);
-    if (e != hipSuccess) return host::fail((int)e, "ray set-up: hipMemsetAsync(workspace) failed: %s", hipGetErrorString(e));
+    if (a.ws_epoch <= 0) {   // the caller does not count its calls: clear both headers with a fill
+        hipError_t e = hipMemsetAsync(a.workspace, 0, 2 * kWsHeaderBytes, st);
+        if (e != hipSuccess) return host::fail((int)e, "ray set-up: hipMemsetAsync(workspace) failed: %s", hipGetErrorString(e));
+    }
     const int bpi = (a.n + 63) / 64;
     hipLaunchKernelGGL(ray_setup_kernel, dim3((unsigned)(bpi * a.B)), dim3(256), 0, st, a, bpi);
     return host::check_launch("ray set-up");
@@ -1041,8 +1045,10 @@ extern "C" int enarf_render_step_fwd(const enarf_prepare_args *prep, const float
     if (!(phases & ENARF_STEP_ALL) || (phases & ~ENARF_STEP_ALL)) return host::fail(ENARF_ERR_ARG, "enarf_render_step_fwd: bad phases %d", phases);
     hipStream_t st = (hipStream_t)stream;
     if (!(phases & ENARF_STEP_PRE)) return dispatch_march(r, st, false);
-    hipError_t e = hipMemsetAsync(r.workspace, 0, kWsHeaderBytes, st);
-    if (e != hipSuccess) return host::fail((int)e, "enarf_render_step_fwd: hipMemsetAsync(workspace) failed: %s", hipGetErrorString(e));
+    if (r.ws_epoch <= 0) {   // the caller does not count its calls: clear both headers with a fill
+        hipError_t e = hipMemsetAsync(r.workspace, 0, 2 * kWsHeaderBytes, st);
+        if (e != hipSuccess) return host::fail((int)e, "enarf_render_step_fwd: hipMemsetAsync(workspace) failed: %s", hipGetErrorString(e));
+    }
     PreParams q;
     q.prep = p; q.rend = r; q.tri = tri_nchw; q.feat_cl = feat_cl; q.tri_B = tri_B; q.ch_total = channels_total;
     q.H = r.H; q.W = r.W;

@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256, kBwdWavesPerSimd) void render_bwd_kernel(const
     float *l_w = lds, *l_bias = l_w + PK_B1, *l_wt = l_bias + 144, *l_parts = l_wt + PKT_FLOATS;
     float *l_canon = l_parts + P * kLdsPartStride, *scratch = l_canon + P * kLdsCanonStride;
     int *l_q = reinterpret_cast<int *>(scratch + SB_QUEUE);
-    rq.init(a.workspace, a.B, n, l_q, tid);
+    rq.init(a.workspace, 0, a.B, n, l_q, tid);      // the backward's own set-up launch runs with epoch 0
     if (tid == 0) rq.pop(0);
     __syncthreads();
     int cur = rq.get(0);

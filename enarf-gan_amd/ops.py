@@ -226,16 +226,43 @@ def query_fwd(points: torch.Tensor, parts: torch.Tensor, canonical_pose: torch.T
 _render_ws = {}
 
 
+_render_epoch = {}
+
+
+def _ws_key(dev: torch.device):
+    return (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+
+
 def _render_workspace(dev: torch.device, B: int, n: int) -> torch.Tensor:
     """Workspace of enarf_render_fwd, cached per (device, stream): launches on one stream are ordered, so they can
     share it; it only grows."""
-    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    key = _ws_key(dev)
     need = int(_lib.load().enarf_render_workspace_bytes(B, n))
     ws = _render_ws.get(key)
     if ws is None or ws.numel() * 4 < need:
         ws = torch.empty((need + 3) // 4, dtype=torch.int32, device=dev)
         _render_ws[key] = ws
+        _render_epoch[key] = 0
     return ws
+
+
+class _Epoch:
+    """ws_epoch bookkeeping of the cached workspace of the current stream (include/enarf_hip.h, enarf_render_args):
+    `with _Epoch(dev) as k:` hands out the epoch for one forward call and, when the call went through, advances the
+    count; anything that raises - and every call that does not keep count, like the backward - falls back to epoch 0."""
+
+    def __init__(self, dev: torch.device, counted: bool = True):
+        self.key, self.counted = _ws_key(dev), counted
+
+    def __enter__(self) -> int:
+        self.k = _render_epoch.get(self.key, 0) if self.counted else 0
+        _render_epoch[self.key] = 0
+        return self.k
+
+    def __exit__(self, exc_type, exc, tb):
+        if exc_type is None:
+            _render_epoch[self.key] = self.k + 1
+        return False
 
 
 class RenderOutputs:
@@ -254,7 +281,9 @@ def render_fwd(image_coord: torch.Tensor, inv_intrinsics: torch.Tensor, parts: t
     a, o, _keep = _render_args(image_coord, inv_intrinsics, parts, canonical_pose, tri_nchw, feat_cl, mlp_pack, Nc, Nf,
                                render_scale, bins, seed, mlp_mode, multiply_density_with_weight, drop_invalid_rays,
                                want_fine, debug, count, early_stop_eps, return_bins)
-    _lib.check(lib.enarf_render_fwd(C.byref(a), _stream(o.color.device)), "enarf_render_fwd")
+    with _Epoch(o.color.device) as k:
+        a.ws_epoch = k
+        _lib.check(lib.enarf_render_fwd(C.byref(a), _stream(o.color.device)), "enarf_render_fwd")
     return o
 
 
@@ -349,9 +378,18 @@ class RenderStep:
 
     def run(self, phases: int = STEP_ALL) -> RenderOutputs:
         t = self.tri
-        rc = self.lib.enarf_render_step_fwd(C.byref(self.pa), _p(t) if self.relayout else None, _p(self.feat_cl),
-                                            t.shape[0], t.shape[1], C.byref(self.ra), phases, _stream(t.device))
-        _lib.check(rc, "enarf_render_step_fwd")
+
+        def call():
+            rc = self.lib.enarf_render_step_fwd(C.byref(self.pa), _p(t) if self.relayout else None, _p(self.feat_cl),
+                                                t.shape[0], t.shape[1], C.byref(self.ra), phases, _stream(t.device))
+            _lib.check(rc, "enarf_render_step_fwd")
+
+        if phases & STEP_PRE:          # a new epoch starts with the pre-march phase; a march-only call stays in it
+            with _Epoch(t.device) as k:
+                self.ra.ws_epoch = k
+                call()
+        else:
+            call()
         return self.out
 
 
@@ -405,7 +443,8 @@ def render_bwd(image_coord, inv_intrinsics, parts, canonical_pose, tri_nchw, fea
     a.rows_dz1, a.rows_dz2, a.rows_dz3 = _p(bufs["dz1"]), _p(bufs["dz2"]), _p(bufs["dz3"])
     a.rows_per_image, a.row_blocks = rows, _p(blocks)
     a.workspace = _p(_render_workspace(dev, B, n))
-    _lib.check(lib.enarf_render_bwd(C.byref(a), _stream(dev)), "enarf_render_bwd")
+    with _Epoch(dev, counted=False):      # the backward's set-up clears the headers itself and uses header 0
+        _lib.check(lib.enarf_render_bwd(C.byref(a), _stream(dev)), "enarf_render_bwd")
     _lib.check(lib.enarf_triplane_unpack_add(_p(gfeat), _p(grad_tri), grad_tri.shape[0], Ct, H, W, _stream(dev)),
                "enarf_triplane_unpack_add")
     dW, db = _weight_grad(bufs, blocks, B, rows, dev)

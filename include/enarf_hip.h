@@ -201,10 +201,15 @@ typedef struct {
     unsigned long long *counters;         /* [0] valid (part,point) pairs sampled, [1] MLP tiles of 16 points run,
                                              [2] rays marched, [3] gather rounds (wave-level), [4] fine tiles skipped by early_stop_eps; (5 x u64) atomically
                                              accumulated; NULL = not counted */
-    void *workspace;                      /* device, >= enarf_render_workspace_bytes(B, n): queue head, per-ray records
-                                             (depth range, candidate parts) and the live-ray list. The call zeroes
-                                             the header on `stream` (hipMemsetAsync); one workspace must not be
-                                             shared by launches that can overlap. */
+    void *workspace;                      /* device, >= enarf_render_workspace_bytes(B, n): two queue headers, per-ray
+                                             records (depth range, candidate parts, direction) and the ray lists; one
+                                             workspace must not be shared by launches that can overlap. */
+    int ws_epoch;                         /* 0: the call clears the queue headers itself (one extra fill launch on
+                                             `stream`) - always safe. k > 0: the caller promises that the previous call
+                                             that used this workspace had ws_epoch k - 1 (any of enarf_render_fwd /
+                                             enarf_render_step_fwd; enarf_render_bwd counts as epoch 0) and completed
+                                             or is ordered before this one on the stream: that call left the header this
+                                             one uses clean, so no fill is launched. */
 } enarf_render_args;
 
 size_t enarf_render_workspace_bytes(int B, int n);

@@ -500,3 +500,33 @@ def test_steps_on_two_streams_do_not_interfere(ops):
     torch.cuda.synchronize()
     for o in outs:
         assert torch.equal(o.color, ref.color) and torch.equal(o.mask, ref.mask)
+
+
+def test_workspace_epochs_alternate_headers_without_a_fill(ops):
+    """ws_epoch protocol (include/enarf_hip.h): consecutive forward calls alternate between the two queue headers, each
+    clearing the other for its successor; a backward in between falls back to epoch 0. Every call gives the same bits."""
+    from enarf_gan_amd import ops as O_
+    sc = Scene(32, 1, "center_fixed", 20)
+    ds = DeviceScene(sc)
+    coord = sc.raw["image_coord"]
+    ref = ds.render(coord, 24, 32, None, seed=3, count=True)
+    key = O_._ws_key(ds.dev)
+    seen = []
+    for i in range(5):
+        seen.append(O_._render_epoch[key])
+        out = ds.render(coord, 24, 32, None, seed=3, count=True)
+        assert torch.equal(out.color, ref.color) and torch.equal(out.counters, ref.counters), i
+    assert seen == list(range(seen[0], seen[0] + 5)) and seen[0] >= 1
+    bins = ds.render(coord, 24, 32, None, seed=3, return_bins=True).taps["bins"]
+    O_.render_bwd(coord.to(ds.dev), ds.inv_K, ds.parts, ds.cpose, ds.tri, ds.feat_cl, ds.pack, 32, bins,
+                  torch.ones(1, 3, 1024, device=ds.dev), torch.ones(1, 1024, device=ds.dev))
+    assert O_._render_epoch[key] == 1                      # the backward used header 0 with its own fill
+    for i in range(3):
+        out = ds.render(coord, 24, 32, None, seed=3, count=True)
+        assert torch.equal(out.color, ref.color) and torch.equal(out.counters, ref.counters)
+    # a launch that has to re-allocate the workspace starts counting again
+    before = O_._render_ws[key].numel()
+    big = Scene(160, 1, "center_fixed", 20)
+    dsb = DeviceScene(big)
+    dsb.render(big.raw["image_coord"], 24, 32, None, seed=3)
+    assert O_._render_ws[key].numel() > before and O_._render_epoch[key] == 1
