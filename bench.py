@@ -58,6 +58,9 @@ def parse():
     ap.add_argument("--unfused", action="store_true",
                     help="issue prepare / re-layout / render as the three separate C-ABI calls (4 launches + memset) "
                          "instead of enarf_render_step_fwd (2 launches + memset)")
+    ap.add_argument("--spinup-ms", type=float, default=40.0,
+                    help="device spin-up during set-up, before the W warm-up steps: the step is repeated until this much "
+                         "wall time has passed, so that short runs (small K and W) are not timed at idle clocks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=4096, help="rays of the same frame per CPU pass (middle band)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="repeat CPU passes until this much time is spent")
@@ -178,6 +181,13 @@ def main():
     torch.cuda.synchronize()
     V, tiles, rays_marched, rounds = [int(x) for x in cnt[:4].tolist()]
 
+    # set-up: bring the device out of its idle clocks (reported in config.spinup_ms; not part of W or K)
+    t_spin = time.perf_counter()
+    while (time.perf_counter() - t_spin) * 1e3 < args.spinup_ms:
+        for _ in range(8):
+            step(0)
+        torch.cuda.synchronize()
+
     for i in range(args.warmup):
         with torch.cuda.stream(streams[i % n_streams]):
             if args.unfused:
@@ -244,7 +254,7 @@ def main():
                                    f"({args.origin}), {B} frame/GPU/step, {'per-frame' if tri.shape[0] > 1 else 'constant'} fp32 tri-plane 256^2x(96+{3 * P}), "
                                    f"in-kernel Philox importance sampling",
                        "sharding": "rays of one frame batch across ranks + all-gather of outputs" if shard else "one frame batch per rank",
-                       "streams": n_streams, "mlp_arith": args.mlp_mode, "early_stop_eps": args.early_stop_eps, "triplane_relayout_in_step": not args.cache_triplane,
+                       "spinup_ms": args.spinup_ms, "streams": n_streams, "mlp_arith": args.mlp_mode, "early_stop_eps": args.early_stop_eps, "triplane_relayout_in_step": not args.cache_triplane,
                        "step": ("enarf_prepare + enarf_triplane_pack + enarf_render_fwd" if args.unfused else
                                 "enarf_render_step_fwd (pre-march launch: re-layout + prepare + ray set-up; then the march)")},
             "roofline": {"bound": "hbm", "kernel": "enarf::render_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
