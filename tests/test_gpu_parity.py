@@ -530,3 +530,44 @@ def test_workspace_epochs_alternate_headers_without_a_fill(ops):
     dsb = DeviceScene(big)
     dsb.render(big.raw["image_coord"], 24, 32, None, seed=3)
     assert O_._render_ws[key].numel() > before and O_._render_epoch[key] == 1
+
+
+def test_in_kernel_importance_sampler_follows_the_reference_law(ops):
+    """The kernel draws its importance samples as sorted uniforms pushed through the inverse CDF of the smoothed
+    coarse weights; the reference draws multinomial bins + uniform jitter and sorts (rendering.py:192-197). Same law:
+    over many seeds the kernel's bins must fall into coarse bin j with probability ws_j / sum(ws) (z-scores ~ N(0,1))
+    and be uniform inside a bin - checked against the oracle's weights AND against the oracle's own sampler."""
+    sc = Scene(32, 1, "center_fixed", 20)
+    ds = DeviceScene(sc)
+    coord = sc.raw["image_coord"][..., 32 * 10:32 * 10 + 256].contiguous()
+    Nc, Nf, S = 48, 64, 40
+    first = ds.render(coord, Nc, Nf, None, seed=1000, debug=True)
+    live = _cpu(first.taps["ray_validity"])[0].bool()
+    assert int(live.sum()) > 60
+    edges = O.linspace_sym(0.0, 1.0, Nc + 1)
+    dmin, dmax = _cpu(first.taps["depth_min"])[0][live], _cpu(first.taps["depth_max"])[0][live]
+    cdepth = dmin[:, None] * (1 - edges) + dmax[:, None] * edges
+    _, cw = O.ray_weights(_cpu(first.taps["coarse_density"])[0][live], cdepth)
+    ws = O.smooth_weights(cw)
+    p = (ws / ws.sum(-1, keepdim=True)).double()                              # (m, Nc)
+    hist = torch.zeros_like(p)
+    frac_sum, frac_n = 0.0, 0
+    for s in range(S):
+        kb = _cpu(ds.render(coord, Nc, Nf, None, seed=1000 + s, return_bins=True).taps["bins"])[0][live].double()
+        j = torch.clamp((kb * Nc).floor().long(), 0, Nc - 1)
+        hist.scatter_add_(1, j, torch.ones_like(kb))
+        frac_sum += float((kb * Nc - j).sum()); frac_n += kb.numel()
+    n_draw = S * Nf
+    exp = n_draw * p
+    ok = exp > 20
+    z2 = ((hist - exp) ** 2 / (n_draw * p * (1 - p)))[ok]
+    assert 0.85 < float(z2.mean()) < 1.15, float(z2.mean())
+    assert abs(frac_sum / frac_n - 0.5) < 0.005
+    # the oracle's own sampler on the same weights has the same statistics
+    g = torch.Generator().manual_seed(0)
+    hist_o = torch.zeros_like(p)
+    for s in range(S):
+        ob = O.draw_bins(ws, Nf, Nc, g).double()
+        hist_o.scatter_add_(1, torch.clamp((ob * Nc).floor().long(), 0, Nc - 1), torch.ones_like(ob))
+    z2o = ((hist_o - exp) ** 2 / (n_draw * p * (1 - p)))[ok]
+    assert abs(float(z2.mean()) - float(z2o.mean())) < 0.15
