@@ -61,6 +61,9 @@ def parse():
     ap.add_argument("--spinup-ms", type=float, default=40.0,
                     help="device spin-up during set-up, before the W warm-up steps: the step is repeated until this much "
                          "wall time has passed, so that short runs (small K and W) are not timed at idle clocks")
+    ap.add_argument("--no-p24", action="store_true",
+                    help="skip the extra timed pass with origin_location center+head (P = 24), which SURVEY.md 8 asks to "
+                         "report beside the shipping P = 23 configuration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=4096, help="rays of the same frame per CPU pass (middle band)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="repeat CPU passes until this much time is spent")
@@ -232,6 +235,36 @@ def main():
         elapsed = float(t.item())
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
 
+    p24 = None
+    if world == 1 and not shard and not args.unfused and args.origin == "center_fixed" and not args.no_p24:
+        # the same step with the head part added (center+head, P = 24): K timed steps after W warm-up steps, serial
+        sc2 = synth.make_scene(S, B, "center+head", args.style_dim, pose_seed=1234, shared_triplane=True)
+        cp2, cb2 = O.register_canonical_pose(sc2["canonical_pose"], sc2["parents"], "center+head")
+        d2 = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in sc2.items()}
+        tri2 = sc2["tri_plane"][:1].contiguous().to(dev)
+        mlp2 = {k: v.to(dev) for k, v in sc2["mlp"].items()}
+        cp2, cb2 = cp2.to(dev), cb2.to(dev)
+        coord2 = d2["image_coord"].reshape(B, 3, n).contiguous()
+        f2 = ops.triplane_pack(tri2)
+        pa2 = torch.empty(B, sc2["num_parts"], 16, device=dev)
+        pk2 = torch.empty(B, ops.mlp_pack_bytes(), dtype=torch.uint8, device=dev)
+
+        def step24():
+            return ops.RenderStep(d2["pose_to_camera"], d2["bone_length"], cb2, d2["z_rend"], mlp2, sc2["parents"], "center+head",
+                                  3.0, coord2, d2["inv_intrinsics"], cp2, tri2, f2, Nc, Nf, parts_out=pa2, pack_out=pk2,
+                                  relayout=not args.cache_triplane, seed=99, mlp_mode=args.mlp_mode, want_fine=True,
+                                  early_stop_eps=args.early_stop_eps).run()
+        for _ in range(max(args.warmup, 1)):
+            step24()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step24()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        p24 = {"workload": f"the same step with origin_location center+head (P = {sc2['num_parts']})", "value": B * n * args.steps / dt,
+               "unit": "rays/s", "ms_per_step": dt / args.steps * 1e3}
+
     if rank == 0:
         rays_per_step = B * n_frame if shard else world * B * n
         value = rays_per_step * args.steps / elapsed
@@ -268,6 +301,8 @@ def main():
                          "mfma_eligible_tflops": q * 12800 / (kern_ms * 1e-3) / 1e12,
                          "mfma_frac_of_bf16_dense_peak": q * 12800 / (kern_ms * 1e-3) / 1e12 / BF16_DENSE_TFLOPS},
         }
+        if p24 is not None:
+            out["p24"] = p24
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(sc, Nc, Nf, min(args.cpu_rays, n), args.cpu_seconds)
         print(json.dumps(out))
