@@ -61,15 +61,32 @@ static_assert(kPackBytes % 16 == 0, "pack must stay 16-byte aligned per image");
 // ---- wave primitives ----------------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
+// wave-wide min / max, every lane gets the result: the same DPP ladder as wave_scan_incl with `fill` (the identity of the
+// operation) where a source lane is out of range or its row is masked off; lane 63 ends up with the full reduction
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_fill_f(float v, float fill) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fill), __builtin_bit_cast(int, v),
+                                                                  CTRL, ROW_MASK, 0xF, false));
+}
 __device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
-    return v;
+    const float inf = __builtin_huge_valf();
+    v = fminf(v, dpp_fill_f<0x111, 0xF>(v, inf));
+    v = fminf(v, dpp_fill_f<0x112, 0xF>(v, inf));
+    v = fminf(v, dpp_fill_f<0x114, 0xF>(v, inf));
+    v = fminf(v, dpp_fill_f<0x118, 0xF>(v, inf));
+    v = fminf(v, dpp_fill_f<0x142, 0xA>(v, inf));
+    v = fminf(v, dpp_fill_f<0x143, 0xC>(v, inf));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
+    const float ninf = -__builtin_huge_valf();
+    v = fmaxf(v, dpp_fill_f<0x111, 0xF>(v, ninf));
+    v = fmaxf(v, dpp_fill_f<0x112, 0xF>(v, ninf));
+    v = fmaxf(v, dpp_fill_f<0x114, 0xF>(v, ninf));
+    v = fmaxf(v, dpp_fill_f<0x118, 0xF>(v, ninf));
+    v = fmaxf(v, dpp_fill_f<0x142, 0xA>(v, ninf));
+    v = fmaxf(v, dpp_fill_f<0x143, 0xC>(v, ninf));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 // DPP data movement (no LDS crossbar round trip as with ds_bpermute): v from the lane `ctrl` names, 0 where the row is
 // masked off or the source lane is out of range
