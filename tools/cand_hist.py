@@ -18,12 +18,13 @@ st = ops.RenderStep(d["pose_to_camera"], d["bone_length"], cbl.to(dev), d["z_ren
 out = st.run()
 torch.cuda.synchronize()
 ws = list(ops._render_ws.values())[0].cpu().numpy().view(np.uint32)
-hdr = ws[:64]
-recs = ws[576:576 + 4 * S * S].reshape(-1, 4)
+hdr_ints = 2 * (16 + 32 + 32 * 16)          # two headers of kWsHeaderBytes / 4 ints (enarf_march.h)
+hdr = ws[:hdr_ints // 2]
+recs = ws[hdr_ints:hdr_ints + 8 * S * S].reshape(-1, 8)
 cand, valid = recs[:, 2], recs[:, 3]
 pc = np.array([bin(int(c)).count("1") for c in cand])
 live = valid == 1
-print("live", live.sum(), "header live", hdr[1], "class counts", hdr[16:48].reshape(8, 4).tolist())
+print("live", live.sum())      # (the header holding this launch's counts is already cleared or reused by later launches)
 print("popcount(cand) histogram over live rays:", np.bincount(pc[live], minlength=24).tolist())
 fv = out.taps["fine_valid"][0].cpu().numpy()        # (n, Nf) bit masks
 cost = np.array([[bin(int(x)).count("1") for x in row] for row in fv[live][:, :]]).max(1)
