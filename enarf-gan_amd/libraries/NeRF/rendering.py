@@ -76,9 +76,6 @@ def render(model, image_coord: torch.Tensor, pose_to_camera: torch.Tensor, inv_i
     `seed` seeds the in-kernel Philox draw (default: a fresh 63-bit number from torch's CPU generator)."""
     if semantic_map:
         raise AssertionError("semantic map rendering will be implemented later")   # rendering.py:298
-    if return_intermediate:
-        raise NotImplementedError("return_intermediate=True (fine_points / fine_density of rendering.py:291) is not "
-                                  "exposed by the fused kernel")
     if pose_to_camera.requires_grad:
         raise NotImplementedError("Currently pose should not be differentiable")   # rendering.py:216-217
     assert pose_to_camera.shape[1] == model.num_bone
@@ -95,6 +92,9 @@ def render(model, image_coord: torch.Tensor, pose_to_camera: torch.Tensor, inv_i
     params = model.mlp.as_dict()
     needs_grad = torch.is_grad_enabled() and (tri_graph.requires_grad or z_rend.requires_grad or
                                               any(p.requires_grad for p in params.values()))
+    if needs_grad and return_intermediate:
+        raise NotImplementedError("return_intermediate=True is served from the kernel's taps and is not differentiable; "
+                                  "call it under torch.no_grad()")
     if needs_grad:
         if mult_w:
             raise NotImplementedError("backward with multiply_density_with_triplane_wieght is not implemented")
@@ -110,10 +110,26 @@ def render(model, image_coord: torch.Tensor, pose_to_camera: torch.Tensor, inv_i
         _pack = model._mlp_pack(z_rend)
     out = ops.render_fwd(image_coord, inv_intrinsics, _parts, model.canonical_pose, tri, feat_cl, _pack, Nc, Nf,
                          render_scale=render_scale, bins=bins, seed=seed, mlp_mode=model.mlp_mode,
-                         multiply_density_with_weight=mult_w, return_bins=True)
+                         multiply_density_with_weight=mult_w, return_bins=True, debug=return_intermediate)
     model.buffers_tensors["bins"] = out.taps["bins"]
     model.buffers_tensors["fine_weights"] = out.fine_weights      # (B, 1, n, Nf-1); zeros for dropped rays
     model.buffers_tensors["fine_depth"] = out.fine_depth          # (B, 1, n, Nf)
+    if return_intermediate:
+        # (fine_points (B, 3, n*Nf), fine_density (B, 1, n*Nf)) of rendering.py:291, for ALL n rays (the reference
+        # compacts batch 1 to the rays that hit; dropped rays hold zero density here) - from the kernel's taps
+        t = out.taps
+        B, n = out.mask.shape
+        coord = image_coord.reshape(B, 3, n).to(torch.float32)
+        Ki = inv_intrinsics.to(torch.float32)
+        if Ki.dim() == 2:
+            Ki = Ki[None].expand(B, -1, -1)
+        ray = torch.einsum("bij,bjn->bin", Ki, coord)
+        b_ = t["bins"][:, None]                                                # (B, 1, n, Nf)
+        start, end = (t["depth_min"][:, None] * ray)[..., None], (t["depth_max"][:, None] * ray)[..., None]
+        fine_points = (start * (1 - b_) + end * b_).reshape(B, 3, n * Nf)
+        fine_density = t["fine_density"].reshape(B, 1, n * Nf)
+        model.buffers_tensors["fine_density"] = fine_density
+        return out.color, out.mask, out.disparity, (fine_points, fine_density)
     return out.color, out.mask, out.disparity
 
 

@@ -72,6 +72,9 @@ class TriNARFGenerator(nn.Module):
         else:
             bg_color = -1
         rendered_color = fg_color + (1 - fg_mask[:, None]) * bg_color
+        if return_intermediate:                          # models/generator.py:109-111
+            fine_points, fine_density = nerf_output[-1]
+            return rendered_color, fg_mask, fine_points, fine_density
         if return_disparity:
             disparity = nerf_output[2] * self.config.nerf_params.coordinate_scale
             return rendered_color, fg_mask, disparity

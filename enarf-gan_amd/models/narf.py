@@ -196,9 +196,12 @@ class TriPlaneNARF(nn.Module):
                                   self.parent_id, self.origin_location, self.coordinate_scale)
         # part-frame count only (the kernel reads `parts`); keeps render()'s shape assertion meaningful
         pose_parts = pose_to_camera.new_empty(pose_to_camera.shape[0], self.num_bone, 4, 4)
-        color, mask, disparity = render(self, sampled_img_coord, pose_parts, inv_intrinsics, render_scale, Nc, Nf,
-                                        return_intermediate=return_intermediate, camera_pose=camera_pose,
-                                        model_input=model_input, _parts=parts, _pack=pack, bins=bins, seed=seed)
+        res = render(self, sampled_img_coord, pose_parts, inv_intrinsics, render_scale, Nc, Nf,
+                     return_intermediate=return_intermediate, camera_pose=camera_pose,
+                     model_input=model_input, _parts=parts, _pack=pack, bins=bins, seed=seed)
+        if return_intermediate:                       # libraries/NeRF/base.py:112-114
+            return res[0], res[1], res[3]
+        color, mask, disparity = res
         if return_disparity:
             return color, mask, disparity
         return color, mask

@@ -154,3 +154,33 @@ def test_density_volume_matches_oracle_grid_sweep():
     assert_close(vol.cpu().reshape(-1), den.reshape(-1), "density volume")
     with pytest.raises(ImportError):
         create_mesh(m, pose, center, voxel, 15, mi)
+
+
+def test_forward_return_intermediate_gives_fine_points_and_density():
+    """NARFBase.forward(return_intermediate=True) (libraries/NeRF/base.py:112-114, rendering.py:291): fine points and
+    fine densities of every ray, against the oracle's taps (rays the reference drops hold zero density)."""
+    sc = Scene(32, 1, "center_fixed", 20)
+    m = _model(sc, Nc=24, Nf=32)
+    s = sc.raw
+    coord = s["image_coord"][..., 32 * 13:32 * 13 + 64].contiguous()
+    g = torch.Generator().manual_seed(4)
+    bins = torch.rand(1, 64, 32, generator=g).sort(-1).values
+    with torch.no_grad():
+        color, mask, (pts, den) = m(1, coord.cuda(), s["pose_to_camera"].cuda(), s["inv_intrinsics"].cuda(), None,
+                                    s["z_rend"].cuda(), s["bone_length"].cuda(), Nc=24, Nf=32, return_intermediate=True,
+                                    bins=bins.cuda())
+    assert pts.shape == (1, 3, 64 * 32) and den.shape == (1, 1, 64 * 32)
+    rc, rm, rd, taps = sc.oracle_render(coord, 24, 32, bins)
+    live = taps["ray_validity"][0]
+    assert_close(color.cpu(), rc, "colour")
+    fd = den.cpu().reshape(1, 64, 32)
+    assert_close(fd[0][live][:, :-1], taps["fine_density"][0][live][:, :-1], "fine density (the last sample is never queried)")
+    assert float(fd[0][~live].abs().max()) == 0.0
+    rd_ = taps["ray_dir"]
+    start, end = taps["depth_min"][:, None] * rd_, taps["depth_max"][:, None] * rd_
+    _, opts = O.fine_points(bins, taps["depth_min"], taps["depth_max"], start, end)
+    assert_close(pts.cpu().reshape(1, 3, 64, 32)[0][:, live], opts[0][:, live], "fine points", 1e-5)
+    with pytest.raises(NotImplementedError):
+        m.train()
+        m(1, coord.cuda(), s["pose_to_camera"].cuda(), s["inv_intrinsics"].cuda(), None, s["z_rend"].cuda(),
+          s["bone_length"].cuda(), Nc=24, Nf=32, return_intermediate=True)
