@@ -552,7 +552,6 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
     unsigned n_pairs = 0, n_tiles = 0, n_rays = 0, n_rounds = 0, n_skipped = 0;
     int qslot = 0;
     const QueryDbg nodbg{nullptr, nullptr, 0, 0};
-    const int Tf = (Nf + 3) >> 2;                          // fine samples per wave (<= 16 SPL)
     const int j4 = lane >> 2;                              // this lane's sample within the wave's tile
     const bool dbgq = (a.dbg_fine_density != nullptr);
 
@@ -729,7 +728,7 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
             for (int t = 0; t < 4 * SPL; ++t) {
                 skip_tile[t] = false;
                 if (a.early_stop_eps > 0.0f) {
-                    const float b_first = wv_get<SPL>(bin, min((t / SPL) * Tf + 16 * (t % SPL), Nf - 1));
+                    const float b_first = wv_get<SPL>(bin, min(16 * t, Nf - 1));
                     const int jbin = min(max((int)(b_first * (float)Nc), 0), Nc - 1);
                     skip_tile[t] = wv_get<SPL>(T, jbin) < a.early_stop_eps;
                 }
@@ -741,30 +740,32 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
         __syncthreads();
         TMR(S, 5);
         TMR4(S, 6);
-        bool skip_tile[SPL];
-#pragma unroll
-        for (int s = 0; s < SPL; ++s) skip_tile[s] = l_skip[wave * SPL + s] != 0;
 
-        // ---- S3: fine pass, wave w owns samples [w Tf, (w+1) Tf); the last sample only closes the last interval
+        // ---- S3: fine pass, in full tiles of 16 samples like the coarse pass (tile T on wave slot T / SPL; Nf = 48 or 32
+        // leave one or two waves without a tile); the last sample only closes the last interval and is never queried
+        {
+            const int slotf = (wave + (int)((rid >> 2) & 3u)) & 3;
 #pragma unroll
-        for (int u = 0; u < SPL; ++u) {
-            if (16 * u >= Tf) break;
-            const int jj = 16 * u + j4, i = wave * Tf + jj;
-            const bool active = (jj < Tf) && (i < (dbgq ? Nf : Nf - 1)) && !skip_tile[u];
-            const float bi = l_bins[min(i, Nf - 1)];
-            const float px = exact_lerp(sx, ex, bi), py = exact_lerp(sy, ey, bi), pz = exact_lerp(sz, ez, bi);
-            f32x4 o;
-            bool ran;
-            uint32_t bits;
-            float wmax;
-            query_tile<MODE, false>(S, l_cand, ncand, px, py, pz, active, lane, o, ran, bits, wmax, nodbg, n_pairs, n_tiles, &n_rounds);
-            const int jm = 16 * u + lane;
-            if (lane < 16 && jm < Tf && wave * Tf + jm < Nf) {
-                const int io = wave * Tf + jm;
-                l_fh[io] = o[0]; l_fh[kMaxSamples + io] = o[1]; l_fh[2 * kMaxSamples + io] = o[2]; l_fh[3 * kMaxSamples + io] = o[3];
+            for (int u = 0; u < SPL; ++u) {
+                const int T = slotf * SPL + u, base = T * 16;
+                if (base >= Nf) break;
+                const int i = base + j4;
+                const bool skip = l_skip[T] != 0;
+                const bool active = (i < (dbgq ? Nf : Nf - 1)) && !skip;
+                const float bi = l_bins[min(i, Nf - 1)];
+                const float px = exact_lerp(sx, ex, bi), py = exact_lerp(sy, ey, bi), pz = exact_lerp(sz, ez, bi);
+                f32x4 o;
+                bool ran;
+                uint32_t bits;
+                float wmax;
+                query_tile<MODE, false>(S, l_cand, ncand, px, py, pz, active, lane, o, ran, bits, wmax, nodbg, n_pairs, n_tiles, &n_rounds);
+                if (lane < 16 && base + lane < Nf) {
+                    const int io = base + lane;
+                    l_fh[io] = o[0]; l_fh[kMaxSamples + io] = o[1]; l_fh[2 * kMaxSamples + io] = o[2]; l_fh[3 * kMaxSamples + io] = o[3];
+                }
+                if (i < Nf && (lane & 3) == 0) { l_fbits[i] = active ? bits : 0u; l_fwmax[i] = wmax; }
+                if (skip && lane == 0) n_skipped += 1;
             }
-            if ((jj < Tf) && (i < Nf) && (lane & 3) == 0) { l_fbits[i] = active ? bits : 0u; l_fwmax[i] = wmax; }
-            if (skip_tile[u] && lane == 0) n_skipped += 1;
         }
         TMR(S, 4);
         TMR4(S, 7);
