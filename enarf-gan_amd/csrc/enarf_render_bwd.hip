@@ -318,7 +318,6 @@ __global__ __launch_bounds__(256, kBwdWavesPerSimd) void render_bwd_kernel(const
     float *l_fh = scratch + SB_FH, *l_dz3 = scratch + SB_DZ3;
     float *ttile = scratch + kBwdScratchFloats + wave * kTTile;     // this wave's atomic-transpose tile
     uint32_t *l_fbits = reinterpret_cast<uint32_t *>(scratch + SB_FBITS);
-    const int Tf = (Nf + 3) >> 2;
     const int j4 = lane >> 2, g4 = lane & 3;
     const size_t mplane = (size_t)a.H * a.W, fplane = mplane * kFeat;
     int qslot = 0;
@@ -352,8 +351,8 @@ __global__ __launch_bounds__(256, kBwdWavesPerSimd) void render_bwd_kernel(const
         const float *bins = a.bins + ((size_t)b * n + ray) * Nf;
 
         // ---- F1: forward of this wave's fine samples (gather layout: lane = 4 sample + chunk)
-        const int i = wave * Tf + j4;
-        const bool active = (j4 < Tf) && (i < Nf - 1);
+        const int i = wave * 16 + j4;                       // full tiles of 16 samples: Nf = 48 keeps wave 3 idle
+        const bool active = i < Nf - 1;
         const float bi = bins[min(i, Nf - 1)];
         const float px = exact_lerp(sx, ex, bi), py = exact_lerp(sy, ey, bi), pz = exact_lerp(sz, ez, bi);
         uint32_t bits;
@@ -370,11 +369,11 @@ __global__ __launch_bounds__(256, kBwdWavesPerSimd) void render_bwd_kernel(const
         } else {
             o = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         }
-        if (lane < Tf && wave * Tf + lane < Nf) {
-            const int io = wave * Tf + lane;
+        if (lane < 16 && wave * 16 + lane < Nf) {
+            const int io = wave * 16 + lane;
             l_fh[io] = o[0]; l_fh[64 + io] = o[1]; l_fh[128 + io] = o[2]; l_fh[192 + io] = o[3];
         }
-        if ((j4 < Tf) && (i < Nf) && g4 == 0) l_fbits[i] = active ? bits : 0u;
+        if (i < Nf && g4 == 0) l_fbits[i] = active ? bits : 0u;
         __syncthreads();
         const int next_ray = rq.get(qslot ^ 1);
         qslot ^= 1;
@@ -418,8 +417,8 @@ __global__ __launch_bounds__(256, kBwdWavesPerSimd) void render_bwd_kernel(const
         // ---- F3 + F4: MLP backward and scatter, per wave (skipped when the tile has no valid sample: then dz3 = 0)
         if (ran) {
             const int mj = lane & 15, mg = lane >> 4;          // MFMA layout: point mj, k-group mg
-            const int ms = min(wave * Tf + mj, Nf - 1);
-            const float dz3v = (mj < Tf) ? l_dz3[mg * 64 + ms] : 0.0f;
+            const int ms = min(wave * 16 + mj, Nf - 1);
+            const float dz3v = (wave * 16 + mj < Nf) ? l_dz3[mg * 64 + ms] : 0.0f;
             bwd_backward_tile(S, T, b, px, py, pz, bits, a1, a2, x, dz3v, lane);
         }
         // the next ray's first barrier orders this ray's LDS reads (l_dz3, l_fh) before their next writes
