@@ -517,11 +517,10 @@ template <int MODE, int SPL>
 __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kernel(const enarf_render_args a, int ablate) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // Persistent workgroups pull consecutive entries of the live-ray list (built by ray_setup_kernel, in image
-    // order) from one atomic queue head: perfect load balance whatever the mix of heavy and light rays, and at any
-    // moment the whole chip works on a window of a few image rows, whose tri-plane footprint stays in every XCD's L2.
+    // Persistent workgroups: each marches one ray at a time, taken off the (band, cost class) lists the set-up pass
+    // filled - heaviest class first chip-wide, own XCD's band first within a class (RayQueue, enarf_march.h).
     const int P = a.P, Nc = a.Nc, Nf = a.Nf, n = a.n;
-    RayQueue rq;                                            // thread 0's view of the XCD-affine queues
+    RayQueue rq;
 
 #if ENARF_TIMERS == 3   // workgroup start / end on the 100 MHz wall clock: how much of the launch is tail
     const unsigned long long wg_t0 = __builtin_amdgcn_s_memrealtime();
