@@ -17,3 +17,13 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built_library():
+    """The tests call through the C ABI: build libenarf_hip.so in-tree if a fresh checkout has not done so yet (hipcc
+    cross-compiles for gfx950 without a GPU; a missing hipcc surfaces as the build error)."""
+    from enarf_gan_amd import build
+    if not os.path.exists(build.LIB):
+        build.build()
+    return build.LIB
