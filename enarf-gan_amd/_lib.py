@@ -44,6 +44,7 @@ class QueryArgs(C.Structure):
         ("mask_planes", _f32p), ("mask_batch_stride", C.c_longlong),
         ("mlp_pack", _f32p), ("density", _f32p), ("color", _f32p), ("valid_bits", _f32p),
         ("dbg_canonical", _f32p), ("dbg_weight", _f32p),
+        ("grid_D", C.c_int), ("grid_center", C.c_float * 3), ("grid_scale", C.c_float),
     ]
 
 

@@ -208,7 +208,18 @@ __global__ __launch_bounds__(256) void query_kernel(const enarf_query_args a, in
         const long long i = base + off + (lane >> 2);
         const bool active = i < N;
         const long long ic = active ? i : N - 1;
-        const float px = pp[ic], py = pp[N + ic], pz = pp[2 * N + ic];
+        float px, py, pz;
+        if (a.grid_D > 0) {   // lattice mode: the point is a function of its index (N = D^3 < 2^31)
+#pragma clang fp contract(off)
+            const unsigned D = (unsigned)a.grid_D, idx = (unsigned)ic;
+            const unsigned ix = idx / (D * D), r = idx - ix * (D * D), iy = r / D, iz = r - iy * D;
+            const int c = (int)(D - 1) / 2;
+            px = ((float)((int)ix - c) / (float)c + a.grid_center[0]) * a.grid_scale;
+            py = ((float)((int)iy - c) / (float)c + a.grid_center[1]) * a.grid_scale;
+            pz = ((float)((int)iz - c) / (float)c + a.grid_center[2]) * a.grid_scale;
+        } else {
+            px = pp[ic]; py = pp[N + ic]; pz = pp[2 * N + ic];
+        }
         QueryDbg dbg{nullptr, nullptr, N, ic};
         if (DBG) {
             dbg.canonical = a.dbg_canonical ? a.dbg_canonical + (size_t)b * a.P * 3 * N : nullptr;
@@ -916,7 +927,7 @@ extern "C" int enarf_mlp_unpack(const void *pack, float *dense, enarf_stream_t s
 
 template <int MODE>
 static int launch_query(const enarf_query_args &a, hipStream_t st) {
-    const int pts_per_wg = 1024;   // 16 tiles of 16 points per wave
+    const int pts_per_wg = 1024;   // 16 tiles of 16 points per wave (larger chunks were slower on the 667^3 sweep: imbalance)
     const long long wgs = (a.N + pts_per_wg - 1) / pts_per_wg;
     if (wgs * a.B > 0x7FFFFFFFll) return host::fail(ENARF_ERR_UNSUPPORTED, "enarf_query_fwd: too many points for one launch");
     const size_t lds = (size_t)lds_total_floats<MODE>(a.P) * 4;
@@ -940,7 +951,13 @@ extern "C" int enarf_query_fwd(const enarf_query_args *args, enarf_stream_t stre
     const enarf_query_args &a = *args;
     if (int rc = check_common("enarf_query_fwd", a.B, a.P, a.H, a.W, a.mlp_mode, a.parts, a.canonical_pose, a.feat_cl,
                               a.mask_planes, a.mlp_pack)) return rc;
-    if (a.N < 0 || !a.points || !a.density) return host::fail(ENARF_ERR_ARG, "enarf_query_fwd: bad N or null points/density");
+    if (a.N < 0 || !a.density) return host::fail(ENARF_ERR_ARG, "enarf_query_fwd: bad N or null density");
+    if (a.grid_D > 0) {
+        if (a.grid_D < 3 || (a.grid_D & 1) == 0 || (long long)a.grid_D * a.grid_D * a.grid_D != a.N || a.N >= (1ll << 31))
+            return host::fail(ENARF_ERR_ARG, "enarf_query_fwd: lattice mode needs an odd grid_D >= 3 with N == grid_D^3 < 2^31");
+    } else if (!a.points) {
+        return host::fail(ENARF_ERR_ARG, "enarf_query_fwd: points is null");
+    }
     if (a.N == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     switch (a.mlp_mode) {

@@ -1,9 +1,9 @@
 """Density sweep behind `create_mesh` (libraries/NARF/mesh_rendering.py:50-81 of the reference).
 
 The reference builds the (2/voxel_size + 1)^3 grid on the host, pushes it through
-`calc_density_and_color_from_camera_coord_v2` in `render_bs` chunks and hands the volume to `mcubes`. Here the grid is
-generated on the device, chunk by chunk, and queried with `enarf_query_fwd` (density only); the volume stays on the
-device. Marching cubes (`mcubes`) and the rasteriser (`pytorch3d`) are third-party and not part of this package:
+`calc_density_and_color_from_camera_coord_v2` in `render_bs` chunks and hands the volume to `mcubes`. Here the lattice
+is generated inside `enarf_query_fwd` (lattice mode, density only, one launch; or chunk by chunk from device tensors when
+`chunk` is given); the volume stays on the device. Marching cubes (`mcubes`) and the rasteriser (`pytorch3d`) are third-party and not part of this package:
 `create_mesh` raises ImportError where the reference would, after the volume is available from `density_volume`.
 """
 from __future__ import annotations
@@ -29,7 +29,7 @@ def _grid_chunk(D: int, start: int, stop: int, center: torch.Tensor, scale: floa
 
 @torch.no_grad()
 def density_volume(model, pose_to_camera: torch.Tensor, center: torch.Tensor, voxel_size: float = 0.003,
-                   model_input: Dict = {}, chunk: int = 1 << 23) -> torch.Tensor:
+                   model_input: Dict = {}, chunk: int = 1 << 31) -> torch.Tensor:
     """(D, D, D) density grid, D = 2 * int(1 / voxel_size) + 1, exactly the tensor the reference feeds to marching
     cubes. pose_to_camera (1, P, 4, 4): part frames with UNSCALED translation (scaled here, on a copy - the reference
     scales its argument in place)."""
@@ -49,6 +49,11 @@ def density_volume(model, pose_to_camera: torch.Tensor, center: torch.Tensor, vo
     pack = model._mlp_pack(model_input["z_rend"])
     mult_w = bool(model.config.multiply_density_with_triplane_wieght)
     total = D * D * D
+    if chunk >= total and total < 2 ** 31:          # one launch, the lattice generated in the kernel (no point tensor)
+        den, _ = ops.query_fwd(None, parts, model.canonical_pose, tri, feat_cl, pack, mlp_mode=model.mlp_mode,
+                               multiply_density_with_weight=mult_w, need_color=False,
+                               grid=(D, center.reshape(3).tolist(), float(model.coordinate_scale)))
+        return den.reshape(D, D, D)
     out = torch.empty(total, dtype=torch.float32, device=dev)
     for s in range(0, total, chunk):
         e = min(s + chunk, total)

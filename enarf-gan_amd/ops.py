@@ -178,15 +178,23 @@ def _plane_strides(tri_nchw: torch.Tensor, feat_cl: torch.Tensor, B: int):
 
 
 # ---------------------------------------------------------------------------------------- a9 query
-def query_fwd(points: torch.Tensor, parts: torch.Tensor, canonical_pose: torch.Tensor, tri_nchw: torch.Tensor,
+def query_fwd(points: Optional[torch.Tensor], parts: torch.Tensor, canonical_pose: torch.Tensor, tri_nchw: torch.Tensor,
               feat_cl: torch.Tensor, mlp_pack: torch.Tensor, mlp_mode: str = "f32",
               multiply_density_with_weight: bool = False, need_color: bool = True, need_valid: bool = False,
-              debug: bool = False):
-    """points (B,3,N) -> density (B,1,N), color (B,3,N) [, valid_bits (B,N) int32 [, canonical, weight]]."""
+              debug: bool = False, grid: Optional[Tuple[int, Sequence[float], float]] = None):
+    """points (B,3,N) -> density (B,1,N), color (B,3,N) [, valid_bits (B,N) int32 [, canonical, weight]].
+
+    grid = (D, centre (3,), scale) with points = None: the D^3 lattice of create_mesh, generated in the kernel."""
     lib = _lib.load()
-    pts = _dev_f32(points, "points")
-    B, _, N = pts.shape
     P = parts.shape[1]
+    if grid is not None:
+        if points is not None:
+            raise ValueError("pass either points or grid")
+        B, N = parts.shape[0], int(grid[0]) ** 3
+        pts = parts                       # device / dtype carrier only
+    else:
+        pts = _dev_f32(points, "points")
+        B, _, N = pts.shape
     tri = _dev_f32(tri_nchw, "tri_plane")
     H, W = tri.shape[2], tri.shape[3]
     mstride, fstride = _plane_strides(tri, feat_cl, B)
@@ -208,7 +216,11 @@ def query_fwd(points: torch.Tensor, parts: torch.Tensor, canonical_pose: torch.T
     a = _lib.QueryArgs()
     a.B, a.N, a.P, a.H, a.W = B, N, P, H, W
     a.mlp_mode, a.multiply_density_with_weight = MLP_MODE[mlp_mode], int(multiply_density_with_weight)
-    a.points, a.parts, a.canonical_pose = _p(pts), _p(parts), _p(_dev_f32(canonical_pose, "canonical_pose"))
+    a.points, a.parts, a.canonical_pose = (None if grid is not None else _p(pts)), _p(parts), _p(_dev_f32(canonical_pose, "canonical_pose"))
+    if grid is not None:
+        a.grid_D, a.grid_scale = int(grid[0]), float(grid[2])
+        for j in range(3):
+            a.grid_center[j] = float(grid[1][j])
     a.feat_cl, a.feat_batch_stride = _p(feat_cl), fstride
     a.mask_planes, a.mask_batch_stride = tri.data_ptr() + PLANE_CH * H * W * 4, mstride
     a.mlp_pack, a.density, a.color, a.valid_bits = _p(mlp_pack), _p(den), _p(col), _p(vb)

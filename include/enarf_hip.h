@@ -152,6 +152,13 @@ typedef struct {
     uint32_t *valid_bits;                 /* device (B, N), bit k = part k valid; may be NULL */
     float *dbg_canonical;                 /* device (B, P, 3, N) canonical coords; may be NULL */
     float *dbg_weight;                    /* device (B, P, N) part probability (0.125 where invalid); may be NULL */
+    /* Lattice mode (points == NULL, grid_D > 0, N == grid_D^3, the same lattice for every image): point i = (ix, iy, iz)
+     * = (i / D^2, i / D % D, i % D) sits at ((ix - c) / c + center_x, ...) * grid_scale with c = (D - 1) / 2 - the grid of
+     * create_mesh (libraries/NARF/mesh_rendering.py:58-59: arange(-c, c + 1) / c, + center, * coordinate_scale),
+     * generated in the kernel instead of streamed from memory. */
+    int grid_D;
+    float grid_center[3];
+    float grid_scale;
 } enarf_query_args;
 
 int enarf_query_fwd(const enarf_query_args *args, enarf_stream_t stream);

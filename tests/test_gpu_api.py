@@ -152,6 +152,8 @@ def test_density_volume_matches_oracle_grid_sweep():
     den, _, valid = O.query(p, sc.pose_scaled, sc.scale, sc.cpose, s["tri_plane"], sc.weights())
     assert int(valid.any(dim=1).sum()) > 50
     assert_close(vol.cpu().reshape(-1), den.reshape(-1), "density volume")
+    lattice = density_volume(m, pose, center, voxel, mi)                # one launch, points generated in the kernel
+    assert torch.equal(lattice, vol), "lattice mode must place the points exactly where the tensor path does"
     with pytest.raises(ImportError):
         create_mesh(m, pose, center, voxel, 15, mi)
 
