@@ -7,7 +7,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "pmc_final")
 tag = sys.argv[1]
 names = {"render_kernel": "march", "pre_march_kernel": "pre", "ray_setup_kernel": "setup"}
-lines = ["# rocprofv3 --pmc (one group per run, with --kernel-trace only) on: python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline",
+lines = ["# rocprofv3 --pmc (one group per run, with --kernel-trace only) on: python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-p24 --spinup-ms 0",
          "# workload C1: 128x128 rays, B=1, Nc 48 + Nf 64, P=23, f16x3; mean over the launches of each kernel",
          "# march = enarf::render_kernel<3,1>, pre = enarf::pre_march_kernel (re-layout + prepare + ray set-up); SQ_* cycle counters are quad-cycles (x4 = cycles)",
          "# FETCH_SIZE / WRITE_SIZE in KB; gfx950 tallies wide reads at half size (MI355X_MICROARCH.md): traffic.json doubles FETCH_SIZE"]
