@@ -135,6 +135,8 @@ SIGNATURES = {
     "enarf_render_fwd": (C.c_int, [C.POINTER(RenderArgs), C.c_void_p]),
     "enarf_render_step_fwd": (C.c_int, [C.POINTER(PrepareArgs), _f32p, _f32p, C.c_int, C.c_int, C.POINTER(RenderArgs),
                                         C.c_int, C.c_void_p]),
+    "enarf_triplane_warp_fwd": (C.c_int, [_f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "enarf_triplane_warp_bwd": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "enarf_weight_grad_workspace_bytes": (C.c_size_t, [C.c_int, C.c_longlong]),
     "enarf_weight_grad": (C.c_int, [C.POINTER(WeightGradArgs), C.c_void_p]),
     "enarf_render_bwd_rows_per_image": (C.c_longlong, [C.c_int, C.c_int]),

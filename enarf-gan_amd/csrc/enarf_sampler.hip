@@ -289,6 +289,86 @@ __global__ __launch_bounds__(256) void sample_bwd_cl32(const float *__restrict__
     }
 }
 
+// ---- deformation-field tri-plane producer (models/narf.py:40-58) -----------------------------------------------------------
+// The reference warps the constant feature planes with F.grid_sample (bilinear, zeros, align_corners False) on the grid
+// (pixel centre + flow) / (W/2) - 1, i.e. it samples plane p at (x + flow_x, y + flow_y), and concatenates the result NCHW.
+// Here the source is the channel-last copy of the constant planes and the output is written channel-last directly - the
+// layout the march reads - so a GAN frame never pays the NCHW -> channel-last re-layout. One lane per channel: every load,
+// store and atomic of a half-wave is one whole 128-B texel line.
+__device__ __forceinline__ Tap2D warp_taps(const float *__restrict__ flow, int b, int p, int x, int y, int H, int W) {
+    const size_t hw = (size_t)H * W;
+    const float fx = flow[((size_t)b * 6 + 2 * p) * hw + (size_t)y * W + x];
+    const float fy = flow[((size_t)b * 6 + 2 * p + 1) * hw + (size_t)y * W + x];
+    float ix, iy;
+    {
+#pragma clang fp contract(off)
+        const float gx = ((float)x + 0.5f + fx) / (0.5f * (float)W) - 1.0f;      // narf.py:49-50 ("/ 128 - 1" at W = 256)
+        const float gy = ((float)y + 0.5f + fy) / (0.5f * (float)H) - 1.0f;
+        ix = ((gx + 1.0f) * (float)W - 1.0f) / 2.0f;
+        iy = ((gy + 1.0f) * (float)H - 1.0f) / 2.0f;
+    }
+    return gs_taps(ix, iy, H, W);
+}
+
+__global__ __launch_bounds__(256) void warp_fwd_kernel(const float *__restrict__ src_cl, const float *__restrict__ flow,
+                                                       float *__restrict__ out_cl, int H, int W) {
+    constexpr int C = 32;
+    const int c = threadIdx.x & 31, p = blockIdx.y, b = blockIdx.z;
+    const long long t = (long long)blockIdx.x * 8 + (threadIdx.x >> 5);
+    const long long hw = (long long)H * W;
+    if (t >= hw) return;
+    const int x = (int)(t % W), y = (int)(t / W);
+    const Tap2D tp = warp_taps(flow, b, p, x, y, H, W);
+    const float *sp = src_cl + (size_t)p * hw * C + c;
+    float v = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v += tp.w[k] * sp[(size_t)tp.o[k] * C];       // out-of-bounds taps weigh zero
+    out_cl[(((size_t)b * 3 + p) * hw + t) * C + c] = v;
+}
+
+__global__ __launch_bounds__(256) void warp_bwd_kernel(const float *__restrict__ g_out_cl, const float *__restrict__ src_cl,
+                                                       const float *__restrict__ flow, float *__restrict__ g_src_cl,
+                                                       float *__restrict__ g_flow, int H, int W) {
+    constexpr int C = 32;
+    const int c = threadIdx.x & 31, p = blockIdx.y, b = blockIdx.z;
+    const long long t0 = (long long)blockIdx.x * 8 + (threadIdx.x >> 5);
+    const long long hw = (long long)H * W;
+    const bool valid = t0 < hw;                      // no early return: the reduction below is wave-wide DPP
+    const long long t = valid ? t0 : hw - 1;
+    const int x = (int)(t % W), y = (int)(t / W);
+    const Tap2D tp = warp_taps(flow, b, p, x, y, H, W);
+    const float g = valid ? g_out_cl[(((size_t)b * 3 + p) * hw + t) * C + c] : 0.0f;
+    const size_t pbase = (size_t)p * hw * C + c;
+    if (g_src_cl && valid) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (tp.inb[k]) atomicAdd(g_src_cl + pbase + (size_t)tp.o[k] * C, tp.w[k] * g);
+    }
+    if (g_flow) {   // d out / d ix, iy as in the grid_sample backward; d ix / d flow_x = (W / 2) / (W / 2) = 1
+        const float ax1 = tp.ix - tp.fx, ax0 = (tp.fx + 1.0f) - tp.ix, ay1 = tp.iy - tp.fy, ay0 = (tp.fy + 1.0f) - tp.iy;
+        float gix = 0.0f, giy = 0.0f;
+        if (tp.inb[0]) { const float v = src_cl[pbase + (size_t)tp.o[0] * C]; gix -= v * ay0 * g; giy -= v * ax0 * g; }
+        if (tp.inb[1]) { const float v = src_cl[pbase + (size_t)tp.o[1] * C]; gix += v * ay0 * g; giy -= v * ax1 * g; }
+        if (tp.inb[2]) { const float v = src_cl[pbase + (size_t)tp.o[2] * C]; gix -= v * ay1 * g; giy += v * ax0 * g; }
+        if (tp.inb[3]) { const float v = src_cl[pbase + (size_t)tp.o[3] * C]; gix += v * ay1 * g; giy += v * ax1 * g; }
+        float r[2] = {gix, giy};
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {   // sum over the 32 channel lanes of the texel (row scans, then row 0 -> 1, 2 -> 3)
+            float v = r[d];
+            v += dpp_f<0x111, 0xF>(v);
+            v += dpp_f<0x112, 0xF>(v);
+            v += dpp_f<0x114, 0xF>(v);
+            v += dpp_f<0x118, 0xF>(v);
+            v += dpp_f<0x142, 0xA>(v);
+            r[d] = v;
+        }
+        if (valid && c == 31) {
+            g_flow[((size_t)b * 6 + 2 * p) * hw + t] = r[0];
+            g_flow[((size_t)b * 6 + 2 * p + 1) * hw + t] = r[1];
+        }
+    }
+}
+
 }  // namespace enarf
 
 using namespace enarf;
@@ -384,4 +464,29 @@ extern "C" int enarf_triplane_sample_bwd(const float *grad_out, const float *inp
     hipLaunchKernelGGL(sample_bwd_direct, dim3((unsigned)((n_pts + 255) / 256), B), dim3(256), 0, (hipStream_t)stream,
                        grad_out, input, grid, grad_input, grad_grid, C, H, W, n_pts, cfg);
     return host::check_launch("enarf_triplane_sample_bwd");
+}
+
+static int check_warp(const char *who, const void *a, const void *b, const void *c, int B, int H, int W) {
+    if (!a || !b || !c) return host::fail(ENARF_ERR_ARG, "%s: null pointer", who);
+    if (B <= 0 || B > 65535 || H <= 0 || W <= 0) return host::fail(ENARF_ERR_ARG, "%s: bad sizes B=%d H=%d W=%d", who, B, H, W);
+    if ((long long)H * W > (1ll << 28)) return host::fail(ENARF_ERR_UNSUPPORTED, "%s: plane too large", who);
+    return 0;
+}
+
+extern "C" int enarf_triplane_warp_fwd(const float *src_cl, const float *flow, float *out_cl, int B, int H, int W,
+                                       enarf_stream_t stream) {
+    if (int rc = check_warp("enarf_triplane_warp_fwd", src_cl, flow, out_cl, B, H, W)) return rc;
+    const unsigned xb = (unsigned)(((long long)H * W + 7) / 8);
+    hipLaunchKernelGGL(warp_fwd_kernel, dim3(xb, 3, B), dim3(256), 0, (hipStream_t)stream, src_cl, flow, out_cl, H, W);
+    return host::check_launch("enarf_triplane_warp_fwd");
+}
+
+extern "C" int enarf_triplane_warp_bwd(const float *g_out_cl, const float *src_cl, const float *flow, float *g_src_cl,
+                                       float *g_flow, int B, int H, int W, enarf_stream_t stream) {
+    if (int rc = check_warp("enarf_triplane_warp_bwd", g_out_cl, src_cl, flow, B, H, W)) return rc;
+    if (!g_src_cl && !g_flow) return 0;
+    const unsigned xb = (unsigned)(((long long)H * W + 7) / 8);
+    hipLaunchKernelGGL(warp_bwd_kernel, dim3(xb, 3, B), dim3(256), 0, (hipStream_t)stream, g_out_cl, src_cl, flow, g_src_cl,
+                       g_flow, H, W);
+    return host::check_launch("enarf_triplane_warp_bwd");
 }

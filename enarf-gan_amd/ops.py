@@ -100,6 +100,35 @@ def triplane_pack(tri_nchw: torch.Tensor, out: Optional[torch.Tensor] = None) ->
     return out
 
 
+def triplane_warp_fwd(src_cl: torch.Tensor, flow: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Deformation-field producer: src_cl (1|-,3,H,W,32) channel-last constant planes, flow (B,6,H,W) -> (B,3,H,W,32)."""
+    lib = _lib.load()
+    src = _dev_f32(src_cl, "src_cl").reshape(3, *src_cl.shape[-3:])
+    fl = _dev_f32(flow, "flow")
+    B, six, H, W = fl.shape
+    if six != 6 or tuple(src.shape) != (3, H, W, FEAT_DIM):
+        raise ValueError(f"flow {tuple(fl.shape)} / src_cl {tuple(src_cl.shape)}: expected (B,6,H,W) and (3,H,W,{FEAT_DIM})")
+    if out is None:
+        out = torch.empty(B, 3, H, W, FEAT_DIM, dtype=torch.float32, device=fl.device)
+    _lib.check(lib.enarf_triplane_warp_fwd(_p(src), _p(fl), _p(out), B, H, W, _stream(fl.device)), "enarf_triplane_warp_fwd")
+    return out
+
+
+def triplane_warp_bwd(g_out_cl: torch.Tensor, src_cl: torch.Tensor, flow: torch.Tensor, need_src: bool = True,
+                      need_flow: bool = True):
+    """-> (g_src_cl (3,H,W,32) or None, g_flow (B,6,H,W) or None)."""
+    lib = _lib.load()
+    g = _dev_f32(g_out_cl, "g_out_cl")
+    src = _dev_f32(src_cl, "src_cl").reshape(3, *src_cl.shape[-3:])
+    fl = _dev_f32(flow, "flow")
+    B, _, H, W = fl.shape
+    gs = torch.zeros_like(src) if need_src else None
+    gf = torch.empty_like(fl) if need_flow else None
+    _lib.check(lib.enarf_triplane_warp_bwd(_p(g), _p(src), _p(fl), _p(gs), _p(gf), B, H, W, _stream(fl.device)),
+               "enarf_triplane_warp_bwd")
+    return gs, gf
+
+
 # ---------------------------------------------------------------------------------------- prepare
 def _prepare_args(pose_to_camera, bone_length, canonical_bone_length, z_rend, mlp, parents, origin_location,
                   coordinate_scale, parts_out, pack_out):

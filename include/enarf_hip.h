@@ -323,6 +323,20 @@ int enarf_prepare_bwd(const enarf_prepare_bwd_args *args, enarf_stream_t stream)
 int enarf_triplane_unpack_add(const float *grad_feat_cl, float *grad_tri_nchw, int B, int channels_total, int H, int W,
                               enarf_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Deformation-field tri-plane producer (models/narf.py:40-58, nerf_params.deformation_field): the constant feature
+ * planes warped by a per-image flow, out[b, p, y, x, :] = bilinear(src[p], x + flow[b, 2p, y, x], y + flow[b, 2p+1, y, x])
+ * (F.grid_sample: bilinear, zeros padding, align_corners False, on the grid (pixel centre + flow) / (W/2) - 1), written
+ * CHANNEL-LAST, ready for enarf_render_fwd (feat_cl per image, part-probability planes shared, mask_batch_stride 0).
+ * src_cl (3, H, W, 32) = enarf_triplane_pack of the constant tri-plane; flow (B, 6, H, W) NCHW; out_cl (B, 3, H, W, 32).
+ * Backward: g_src_cl (3, H, W, 32) is accumulated into (zero-fill it; fold it back with enarf_triplane_unpack_add),
+ * g_flow (B, 6, H, W) is written; either may be NULL.
+ * --------------------------------------------------------------------------------------------- */
+int enarf_triplane_warp_fwd(const float *src_cl, const float *flow, float *out_cl, int B, int H, int W,
+                            enarf_stream_t stream);
+int enarf_triplane_warp_bwd(const float *g_out_cl, const float *src_cl, const float *flow, float *g_src_cl,
+                            float *g_flow, int B, int H, int W, enarf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -571,3 +571,34 @@ def test_in_kernel_importance_sampler_follows_the_reference_law(ops):
         hist_o.scatter_add_(1, torch.clamp((ob * Nc).floor().long(), 0, Nc - 1), torch.ones_like(ob))
     z2o = ((hist_o - exp) ** 2 / (n_draw * p * (1 - p)))[ok]
     assert abs(float(z2.mean()) - float(z2o.mean())) < 0.15
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 32, 40), (1, 256, 256)])
+def test_deformation_field_producer_vs_grid_sample(ops, B, H, W):
+    """enarf_triplane_warp_fwd / _bwd (models/narf.py:40-58): the constant feature planes warped by a flow, written
+    channel-last, against F.grid_sample (bilinear, zeros, align_corners False) and its autograd; flows of a few texels,
+    some pointing out of the plane."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(H)
+    planes = torch.randn(1, 96, H, W, generator=g)
+    flow = 3.0 * torch.randn(B, 6, H, W, generator=g)
+    flow[:, :, :2] -= 6.0                                  # rows that sample above the plane
+    gout = torch.randn(B, 3, H, W, 32, generator=g)
+
+    x, f = planes.clone().requires_grad_(True), flow.clone().requires_grad_(True)
+    gx = (torch.arange(W) + 0.5 + f[:, 0::2]) / (W / 2) - 1
+    gy = (torch.arange(H)[:, None] + 0.5 + f[:, 1::2]) / (H / 2) - 1
+    grid = torch.stack([gx, gy], dim=-1).reshape(B * 3, H, W, 2)
+    src = x.reshape(1, 3, 32, H, W).expand(B, -1, -1, -1, -1).reshape(B * 3, 32, H, W)
+    ref = F.grid_sample(src, grid, mode="bilinear", padding_mode="zeros", align_corners=False)
+    ref_cl = ref.reshape(B, 3, 32, H, W).permute(0, 1, 3, 4, 2)
+    (ref_cl * gout).sum().backward()
+
+    src_cl = ops.triplane_pack(planes.cuda())                         # (1, 3, H, W, 32)
+    out = ops.triplane_warp_fwd(src_cl, flow.cuda())
+    assert_close(_cpu(out), ref_cl.detach(), "warped planes", 1e-5)
+    gs, gf = ops.triplane_warp_bwd(gout.cuda(), src_cl, flow.cuda())
+    assert_close(_cpu(gs).permute(0, 3, 1, 2).reshape(1, 96, H, W), x.grad, "d planes", 1e-5)
+    assert_close(_cpu(gf), f.grad, "d flow", 1e-5)
+    only_flow = ops.triplane_warp_bwd(gout.cuda(), src_cl, flow.cuda(), need_src=False)
+    assert only_flow[0] is None and torch.equal(only_flow[1], gf)
