@@ -88,10 +88,11 @@ def render(model, image_coord: torch.Tensor, pose_to_camera: torch.Tensor, inv_i
     cfg = model.config
     mult_w = bool(cfg.multiply_density_with_triplane_wieght)
     z_rend = model_input["z_rend"]
-    tri_graph = model._tri_plane_graph(model_input)        # tri-plane as the autograd graph sees it
     params = model.mlp.as_dict()
-    needs_grad = torch.is_grad_enabled() and (tri_graph.requires_grad or z_rend.requires_grad or
-                                              any(p.requires_grad for p in params.values()))
+    needs_grad = False
+    if torch.is_grad_enabled():
+        tri_graph = model._tri_plane_graph(model_input)    # tri-plane as the autograd graph sees it
+        needs_grad = (tri_graph.requires_grad or z_rend.requires_grad or any(p.requires_grad for p in params.values()))
     if needs_grad and return_intermediate:
         raise NotImplementedError("return_intermediate=True is served from the kernel's taps and is not differentiable; "
                                   "call it under torch.no_grad()")

@@ -103,8 +103,11 @@ class TriPlaneNARF(nn.Module):
         self.mlp_mode = getattr(config, "mlp_mode", "f16x3") if not isinstance(config, dict) else config.get("mlp_mode", "f16x3")
         if config.constant_triplane or config.deformation_field:
             self.tri_plane = nn.Parameter(torch.zeros(1, 32 * 3 + self.num_bone * 3, 256, 256))
+        self.flow_generator = None         # deformation_field: assign a callable (z, *args, **kwargs) -> flow (B, 6, 256, 256)
         if config.constant_triplane:
             self.tri_plane_gen = lambda z, *args, **kwargs: self.tri_plane.expand(z.shape[0], -1, -1, -1)
+        elif config.deformation_field:
+            self.tri_plane_gen = self._warped_tri_plane     # models/narf.py:40-58 with the HIP warp producer
         else:
             self.tri_plane_gen = None      # the StyleGAN2-ADA producer is out of scope: assign a callable
         self.mlp = StyledMLP(32, 64, 4, style_dim=self.z2_dim)
@@ -142,11 +145,42 @@ class TriPlaneNARF(nn.Module):
             return self.tri_plane.expand(bs, -1, -1, -1)
         return self.tri_plane_gen(z, bone_length, truncation_psi=truncation_psi)
 
+    # ---- deformation-field producer (models/narf.py:40-58) ----------------------------------------------------------
+    def _flow(self, z, *args, **kwargs) -> torch.Tensor:
+        if self.flow_generator is None:
+            raise NotImplementedError("deformation_field: the StyleGAN2 flow generator is out of scope (SURVEY.md §2): "
+                                      "assign model.flow_generator, a callable (z, ...) -> flow (B, 6, 256, 256)")
+        return self.flow_generator(z, *args, **kwargs)
+
+    def _constant_planes_cl(self) -> torch.Tensor:
+        """Channel-last copy of the constant feature planes, re-laid out once per parameter version."""
+        tri = self.tri_plane.detach()
+        key = (tri.data_ptr(), tri._version, tuple(tri.shape))
+        if self._cl_cache is None or self._cl_cache[0] != key:
+            self._cl_cache = (key, ops.triplane_pack(tri))
+        return self._cl_cache[1]
+
+    def _warped_tri_plane(self, z, *args, **kwargs) -> torch.Tensor:
+        """The reference's `warp` closure: (B, 96 + 3P, 256, 256) NCHW, differentiable w.r.t. the tri-plane parameter
+        and the flow (the autograd path and `buffers_tensors`; rendering without gradients takes `_tri_plane_pair`'s
+        direct channel-last route instead)."""
+        flow = self._flow(z, *args, **kwargs)
+        warped = _WarpFunction.apply(self.tri_plane, flow)                                  # (B, 96, H, W)
+        return torch.cat([warped, self.tri_plane[:, 96:].expand(flow.shape[0], -1, -1, -1)], dim=1)
+
     def _tri_plane_pair(self, model_input: Dict):
         """(tri-plane NCHW (1 or B images), channel-last feature planes) for this call.
 
-        A constant tri-plane (one image shared by the batch) is re-laid out once per parameter version."""
+        A constant tri-plane (one image shared by the batch) is re-laid out once per parameter version; with a
+        deformation field the constant planes are warped straight into the channel-last layout (one image per flow)
+        and the part-probability planes stay shared."""
         tri = model_input.get("tri_plane_feature")
+        if tri is None and self.config.deformation_field:
+            flow = self._flow(model_input.get("z"), model_input["bone_length"],
+                              truncation_psi=model_input.get("truncation_psi", 1)).detach()
+            feat_cl = ops.triplane_warp_fwd(self._constant_planes_cl(), flow)
+            self.buffers_tensors["tri_plane_feature"] = None      # (not materialised NCHW on this route)
+            return self.tri_plane.detach(), feat_cl
         if tri is None:
             tri = self.compute_tri_plane_feature(model_input.get("z"), model_input["bone_length"],
                                                  model_input.get("truncation_psi", 1))
@@ -249,6 +283,33 @@ class TriPlaneNARF(nn.Module):
 
 
 _MLP_LEAVES = ("conv.weight", "conv.modulation.weight", "conv.modulation.bias", "bias")
+
+
+class _WarpFunction(torch.autograd.Function):
+    """Constant tri-plane parameter (1, 96 + 3P, H, W) + flow (B, 6, H, W) -> warped feature planes (B, 96, H, W) NCHW:
+    enarf_triplane_pack + enarf_triplane_warp_fwd forward, enarf_triplane_warp_bwd + enarf_triplane_unpack_add backward."""
+
+    @staticmethod
+    def forward(ctx, tri, flow):
+        tri_c, fl = tri.detach().contiguous(), flow.detach().contiguous().float()
+        src_cl = ops.triplane_pack(tri_c)
+        out_cl = ops.triplane_warp_fwd(src_cl, fl)
+        B, _, H, W, C = out_cl.shape
+        ctx.save_for_backward(src_cl, fl)
+        ctx.tri_shape = tuple(tri_c.shape)
+        return out_cl.permute(0, 1, 4, 2, 3).reshape(B, 3 * C, H, W)
+
+    @staticmethod
+    def backward(ctx, g):
+        src_cl, fl = ctx.saved_tensors
+        B, _, H, W = fl.shape
+        g_cl = g.reshape(B, 3, 32, H, W).permute(0, 1, 3, 4, 2).contiguous()
+        gs, gf = ops.triplane_warp_bwd(g_cl, src_cl, fl, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        g_tri = None
+        if gs is not None:
+            g_tri = torch.zeros(ctx.tri_shape, dtype=torch.float32, device=fl.device)
+            ops.triplane_unpack_add(gs.reshape(1, 3, H, W, 32), g_tri)
+        return g_tri, gf
 
 
 class _QueryFunction(torch.autograd.Function):

@@ -100,6 +100,16 @@ def triplane_pack(tri_nchw: torch.Tensor, out: Optional[torch.Tensor] = None) ->
     return out
 
 
+def triplane_unpack_add(grad_feat_cl: torch.Tensor, grad_tri_nchw: torch.Tensor) -> torch.Tensor:
+    """grad_tri[:, :96] += channel-last gradient (B, 3, H, W, 32) (the inverse re-layout)."""
+    lib = _lib.load()
+    g = _dev_f32(grad_feat_cl, "grad_feat_cl")
+    B, Ct, H, W = grad_tri_nchw.shape
+    _lib.check(lib.enarf_triplane_unpack_add(_p(g), _p(grad_tri_nchw), B, Ct, H, W, _stream(g.device)),
+               "enarf_triplane_unpack_add")
+    return grad_tri_nchw
+
+
 def triplane_warp_fwd(src_cl: torch.Tensor, flow: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Deformation-field producer: src_cl (1|-,3,H,W,32) channel-last constant planes, flow (B,6,H,W) -> (B,3,H,W,32)."""
     lib = _lib.load()
