@@ -65,6 +65,42 @@ class _RenderFunction(torch.autograd.Function):
         return (None, grad_tri, dz) + tuple(grads)
 
 
+class _RenderFunctionCL(torch.autograd.Function):
+    """The same march for producers that emit channel-last feature planes (the deformation-field warp): differentiable
+    inputs are the NCHW tri-plane that holds the part-probability planes (1 or B images), the channel-last feature planes
+    (B, 3, H, W, 32), z_rend and the StyledMLP tensors. No NCHW <-> channel-last copy in either direction."""
+
+    @staticmethod
+    def forward(ctx, k, tri, feat_cl, z_rend, *params):
+        mlp = {f"layers.{i}.{leaf}": params[4 * i + j] for i in range(3) for j, leaf in enumerate(_MLP_LEAVES)}
+        tri_c, feat_c = tri.detach().contiguous(), feat_cl.detach().contiguous()
+        pack = k["pack_fn"](z_rend.detach(), {n: t.detach() for n, t in mlp.items()})
+        out = ops.render_fwd(k["image_coord"], k["inv_intrinsics"], k["parts"], k["canonical_pose"], tri_c, feat_c, pack,
+                             k["Nc"], k["Nf"], render_scale=k["render_scale"], bins=k["bins"], seed=k["seed"],
+                             mlp_mode=k["mlp_mode"], return_bins=True)
+        bins_used = out.taps["bins"]
+        ctx.k = k
+        ctx.save_for_backward(tri_c, feat_c, pack, bins_used, z_rend.detach(), *[p.detach() for p in params])
+        ctx.mark_non_differentiable(out.fine_weights, out.fine_depth, bins_used)
+        return out.color, out.mask, out.disparity, out.fine_weights, out.fine_depth, bins_used
+
+    @staticmethod
+    def backward(ctx, g_color, g_mask, g_disp, _gfw, _gfd, _gb):
+        k = ctx.k
+        tri_c, feat_c, pack, bins_used, z_rend = ctx.saved_tensors[:5]
+        params = ctx.saved_tensors[5:]
+        mlp = {f"layers.{i}.{leaf}": params[4 * i + j] for i in range(3) for j, leaf in enumerate(_MLP_LEAVES)}
+        grad_tri, dW, db, gfeat = ops.render_bwd(k["image_coord"], k["inv_intrinsics"], k["parts"], k["canonical_pose"],
+                                                 tri_c, feat_c, pack, k["Nf"], bins_used, g_color, g_mask, g_disp,
+                                                 render_scale=k["render_scale"], feat_grad_channel_last=True)
+        pg, dz = ops.prepare_bwd(z_rend, mlp, dW)
+        grads = []
+        for i in range(3):
+            grads += [pg[f"layers.{i}.conv.weight"], pg[f"layers.{i}.conv.modulation.weight"],
+                      pg[f"layers.{i}.conv.modulation.bias"], db[i].reshape(params[4 * i + 3].shape)]
+        return (None, grad_tri, gfeat, dz) + tuple(grads)
+
+
 def render(model, image_coord: torch.Tensor, pose_to_camera: torch.Tensor, inv_intrinsics: torch.Tensor,
            render_scale: float = 1, Nc: int = 64, Nf: int = 128, semantic_map: bool = False,
            return_intermediate: bool = False, camera_pose: Optional[torch.Tensor] = None,
@@ -90,9 +126,15 @@ def render(model, image_coord: torch.Tensor, pose_to_camera: torch.Tensor, inv_i
     z_rend = model_input["z_rend"]
     params = model.mlp.as_dict()
     needs_grad = False
+    cl_route = bool(cfg.deformation_field) and model_input.get("tri_plane_feature") is None
     if torch.is_grad_enabled():
-        tri_graph = model._tri_plane_graph(model_input)    # tri-plane as the autograd graph sees it
-        needs_grad = (tri_graph.requires_grad or z_rend.requires_grad or any(p.requires_grad for p in params.values()))
+        if cl_route:     # the producer emits channel-last planes: (part-probability planes NCHW, feature planes channel-last)
+            tri_graph, feat_graph = model._tri_plane_pair_graph(model_input)
+            needs_grad = feat_graph.requires_grad
+        else:
+            tri_graph = model._tri_plane_graph(model_input)    # tri-plane as the autograd graph sees it
+        needs_grad = (needs_grad or tri_graph.requires_grad or z_rend.requires_grad or
+                      any(p.requires_grad for p in params.values()))
     if needs_grad and return_intermediate:
         raise NotImplementedError("return_intermediate=True is served from the kernel's taps and is not differentiable; "
                                   "call it under torch.no_grad()")
@@ -103,8 +145,12 @@ def render(model, image_coord: torch.Tensor, pose_to_camera: torch.Tensor, inv_i
                  canonical_pose=model.canonical_pose, Nc=Nc, Nf=Nf, render_scale=float(render_scale), bins=bins, seed=seed,
                  mlp_mode=model.mlp_mode, pack_fn=model._mlp_pack_from)
         flat = [params[f"layers.{i}.{leaf}"] for i in range(3) for leaf in _MLP_LEAVES]
-        color, mask, disparity, fw, fd, bins_used = _RenderFunction.apply(k, tri_graph, z_rend, *flat)
-        model.buffers_tensors.update(fine_weights=fw, fine_depth=fd, bins=bins_used, tri_plane_feature=tri_graph)
+        if cl_route:
+            color, mask, disparity, fw, fd, bins_used = _RenderFunctionCL.apply(k, tri_graph, feat_graph, z_rend, *flat)
+            model.buffers_tensors.update(fine_weights=fw, fine_depth=fd, bins=bins_used, tri_plane_feature=None)
+        else:
+            color, mask, disparity, fw, fd, bins_used = _RenderFunction.apply(k, tri_graph, z_rend, *flat)
+            model.buffers_tensors.update(fine_weights=fw, fine_depth=fd, bins=bins_used, tri_plane_feature=tri_graph)
         return color, mask, disparity
     tri, feat_cl = model._tri_plane_pair(model_input)
     if _pack is None:

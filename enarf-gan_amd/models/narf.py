@@ -168,6 +168,12 @@ class TriPlaneNARF(nn.Module):
         warped = _WarpFunction.apply(self.tri_plane, flow)                                  # (B, 96, H, W)
         return torch.cat([warped, self.tri_plane[:, 96:].expand(flow.shape[0], -1, -1, -1)], dim=1)
 
+    def _tri_plane_pair_graph(self, model_input: Dict):
+        """Deformation field under autograd: (the tri-plane parameter - it holds the part-probability planes -, warped
+        feature planes channel-last (B, 3, H, W, 32)), both differentiable; no NCHW copy of the warped planes."""
+        flow = self._flow(model_input.get("z"), model_input["bone_length"], truncation_psi=model_input.get("truncation_psi", 1))
+        return self.tri_plane, _WarpCLFunction.apply(self.tri_plane, flow)
+
     def _tri_plane_pair(self, model_input: Dict):
         """(tri-plane NCHW (1 or B images), channel-last feature planes) for this call.
 
@@ -305,6 +311,29 @@ class _WarpFunction(torch.autograd.Function):
         B, _, H, W = fl.shape
         g_cl = g.reshape(B, 3, 32, H, W).permute(0, 1, 3, 4, 2).contiguous()
         gs, gf = ops.triplane_warp_bwd(g_cl, src_cl, fl, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        g_tri = None
+        if gs is not None:
+            g_tri = torch.zeros(ctx.tri_shape, dtype=torch.float32, device=fl.device)
+            ops.triplane_unpack_add(gs.reshape(1, 3, H, W, 32), g_tri)
+        return g_tri, gf
+
+
+class _WarpCLFunction(torch.autograd.Function):
+    """As _WarpFunction, but the warped planes stay channel-last (B, 3, H, W, 32): what the march reads."""
+
+    @staticmethod
+    def forward(ctx, tri, flow):
+        tri_c, fl = tri.detach().contiguous(), flow.detach().contiguous().float()
+        src_cl = ops.triplane_pack(tri_c)
+        ctx.save_for_backward(src_cl, fl)
+        ctx.tri_shape = tuple(tri_c.shape)
+        return ops.triplane_warp_fwd(src_cl, fl)
+
+    @staticmethod
+    def backward(ctx, g_cl):
+        src_cl, fl = ctx.saved_tensors
+        H, W = fl.shape[2:]
+        gs, gf = ops.triplane_warp_bwd(g_cl.contiguous(), src_cl, fl, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
         g_tri = None
         if gs is not None:
             g_tri = torch.zeros(ctx.tri_shape, dtype=torch.float32, device=fl.device)

@@ -452,10 +452,13 @@ def render_step_fwd(*args, **kw) -> RenderOutputs:
 
 # ---------------------------------------------------------------------------------------- backward
 def render_bwd(image_coord, inv_intrinsics, parts, canonical_pose, tri_nchw, feat_cl, mlp_pack, Nf, bins,
-               g_color, g_mask, g_disparity=None, render_scale: float = 1.0, drop_invalid_rays: Optional[bool] = None):
+               g_color, g_mask, g_disparity=None, render_scale: float = 1.0, drop_invalid_rays: Optional[bool] = None,
+               feat_grad_channel_last: bool = False):
     """Backward of render_fwd w.r.t. the tri-plane and the per-image demodulated MLP weights / biases.
 
     Returns (grad_tri (same batch as tri_nchw: 1 for a shared tri-plane), dW [3 x (B,out,in)], db [3 x (out,)]).
+    feat_grad_channel_last: the feature-plane gradient stays channel-last (same shape as feat_cl) and is returned as a
+    fourth value instead of being folded into grad_tri[:, :96] (for producers that emit channel-last planes).
     The weight gradients are formed from the kernel's per-tile rows by enarf_weight_grad (MFMA split-K, no host sync)."""
     lib = _lib.load()
     coord = _dev_f32(image_coord, "image_coord")
@@ -496,9 +499,12 @@ def render_bwd(image_coord, inv_intrinsics, parts, canonical_pose, tri_nchw, fea
     a.workspace = _p(_render_workspace(dev, B, n))
     with _Epoch(dev, counted=False):      # the backward's set-up clears the headers itself and uses header 0
         _lib.check(lib.enarf_render_bwd(C.byref(a), _stream(dev)), "enarf_render_bwd")
-    _lib.check(lib.enarf_triplane_unpack_add(_p(gfeat), _p(grad_tri), grad_tri.shape[0], Ct, H, W, _stream(dev)),
-               "enarf_triplane_unpack_add")
+    if not feat_grad_channel_last:
+        _lib.check(lib.enarf_triplane_unpack_add(_p(gfeat), _p(grad_tri), grad_tri.shape[0], Ct, H, W, _stream(dev)),
+                   "enarf_triplane_unpack_add")
     dW, db = _weight_grad(bufs, blocks, B, rows, dev)
+    if feat_grad_channel_last:
+        return grad_tri, dW, db, gfeat
     return grad_tri, dW, db
 
 
