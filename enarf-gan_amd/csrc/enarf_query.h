@@ -10,6 +10,9 @@
 #pragma once
 #include "enarf_device.h"
 
+#ifndef ENARF_ROUND_PRIO
+#define ENARF_ROUND_PRIO 2
+#endif
 #ifndef ENARF_PLANE_SERIAL
 #define ENARF_PLANE_SERIAL 2
 #endif
@@ -490,6 +493,11 @@ __device__ __forceinline__ void query_tile(const QueryCtx &S, const int *cand_li
     const unsigned fplane_b = (unsigned)(mplane * kFeat * sizeof(float));        // bytes per feature plane
     const unsigned goff = (unsigned)g << 5;                                       // this lane's 32-B chunk
     uint32_t rem = b;
+#if ENARF_ROUND_PRIO
+    // the gather rounds issue ahead of the other waves' MLP / sampling / compositing (+1.8 % at one frame; raising the
+    // candidate tests too, or the MLP instead, gains less)
+    __builtin_amdgcn_s_setprio(ENARF_ROUND_PRIO);
+#endif
     while (true) {
         const uint64_t bal = __ballot(rem != 0);
         if (bal == 0) break;
@@ -635,6 +643,9 @@ __device__ __forceinline__ void query_tile(const QueryCtx &S, const int *cand_li
         TMR(S, 3);
     }
 
+#if ENARF_ROUND_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     ran = (__ballot(b != 0) != 0) && !(S.ablate & 4);
     if (ran) {
         n_tiles += 1;

@@ -4,6 +4,9 @@
 #include "enarf_host.h"
 #include <cstdlib>
 
+#ifndef ENARF_S2_PRIO
+#define ENARF_S2_PRIO 3
+#endif
 #ifndef ENARF_RENDER_WAVES_PER_SIMD
 #define ENARF_RENDER_WAVES_PER_SIMD 3
 #endif
@@ -662,6 +665,9 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
         float *l_bins = scratch + SC_BINS;
         int *l_skip = reinterpret_cast<int *>(scratch + SC_BINS + kMaxSamples);
         if (wave == spare_wave) {
+#if ENARF_S2_PRIO
+            __builtin_amdgcn_s_setprio(ENARF_S2_PRIO);     // three waves wait at the next barrier for this one
+#endif
             float bin[SPL];
             bool skip_tile[4 * SPL];
 
@@ -744,6 +750,9 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
                 }
                 if (lane == 0) l_skip[t] = skip_tile[t] ? 1 : 0;
             }
+#if ENARF_S2_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
         }
         TMR(S, 6);
         TMR4(S, 2);
