@@ -56,8 +56,8 @@ def parse():
                          "(sharding.rays_for_rank) and the 5 floats per ray are all-gathered on every rank each step "
                          "(SURVEY.md 8e, single DSO frame); default is weak scaling, one frame batch per rank")
     ap.add_argument("--unfused", action="store_true",
-                    help="issue prepare / re-layout / render as the three separate C-ABI calls (4 launches + memset) "
-                         "instead of enarf_render_step_fwd (2 launches + memset)")
+                    help="issue prepare / re-layout / render as the three separate C-ABI calls (4 launches) "
+                         "instead of enarf_render_step_fwd (2 launches)")
     ap.add_argument("--spinup-ms", type=float, default=40.0,
                     help="device spin-up during set-up, before the W warm-up steps: the step is repeated until this much "
                          "wall time has passed, so that short runs (small K and W) are not timed at idle clocks")
