@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams the steps alternate over, each with its own intermediates (part frames, MLP packs, "
                          "channel-last planes, workspace). With 2, the pre-march launch of step i+1 fills the CUs that the "
-                         "persistent march of step i frees in its tail (+7 %% rays/s), but event-bracketed kernel times then "
+                         "persistent march of step i frees in its tail (+4 %% rays/s), but event-bracketed kernel times then "
                          "include the overlap, so the default - and the roofline figure - is strictly serial steps")
     ap.add_argument("--shard-frame", action="store_true",
                     help="N > 1: strong scaling of ONE frame batch - every rank marches its contiguous share of the rays "
