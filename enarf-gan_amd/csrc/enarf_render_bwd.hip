@@ -226,9 +226,10 @@ __device__ __forceinline__ void bwd_backward_tile(const QueryCtx &S, const BwdTi
 
     // ---- F4: second pass over the pairs: d part-probability and d feature texels
     uint32_t rem = (ENARF_BWD_ABLATE & 4) ? 0u : bits;
+    __builtin_amdgcn_s_setprio(2);          // memory rounds ahead of the other waves' MFMA phases (as in the forward)
     while (true) {
         const uint64_t bal = __ballot(rem != 0);
-        if (bal == 0) break;
+        if (bal == 0) { __builtin_amdgcn_s_setprio(0); break; }
         const bool act = rem != 0;
         const int k = act ? __builtin_ctz(rem) : 0;
         rem &= rem - 1;
