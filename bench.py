@@ -64,6 +64,9 @@ def parse():
     ap.add_argument("--no-p24", action="store_true",
                     help="skip the extra timed pass with origin_location center+head (P = 24), which SURVEY.md 8 asks to "
                          "report beside the shipping P = 23 configuration")
+    ap.add_argument("--allow-variant", action="store_true", help="measurement only: permit --variant")
+    ap.add_argument("--variant", default=None, help="path of another build of the same ABI (tools/build_variant.sh); "
+                                                     "refused without --allow-variant")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=4096, help="rays of the same frame per CPU pass (middle band)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="repeat CPU passes until this much time is spent")
@@ -101,8 +104,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N > 1 with `python -m torch.distributed.run "
+                         f"--nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus} ...`")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU path in enarf_gan_amd")
     # one rank per GPU; a rehearsal with more ranks than GPUs (ENARF_BENCH_BACKEND=gloo on a 1-GPU box) wraps around
@@ -118,6 +122,13 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    from enarf_gan_amd import _lib
+    if os.environ.get("ENARF_LIB"):
+        raise SystemExit("ENARF_LIB is set: the product ignores it; use --allow-variant --variant PATH for an A/B run")
+    if args.variant:
+        if not args.allow_variant:
+            raise SystemExit("--variant needs --allow-variant (the default bench measures the in-tree library only)")
+        _lib.use_variant(args.variant)
     from enarf_gan_amd import ops, synth
     from oracle import enarf_oracle as O   # only for the canonical-pose buffers of the synthetic scene and the cpu_baseline leg
 
@@ -287,7 +298,7 @@ def main():
                                    f"({args.origin}), {B} frame/GPU/step, {'per-frame' if tri.shape[0] > 1 else 'constant'} fp32 tri-plane 256^2x(96+{3 * P}), "
                                    f"in-kernel Philox importance sampling",
                        "sharding": "rays of one frame batch across ranks + all-gather of outputs" if shard else "one frame batch per rank",
-                       "spinup_ms": args.spinup_ms, "streams": n_streams, "mlp_arith": args.mlp_mode, "early_stop_eps": args.early_stop_eps, "triplane_relayout_in_step": not args.cache_triplane,
+                       "library": _lib.library_info(), "spinup_ms": args.spinup_ms, "streams": n_streams, "mlp_arith": args.mlp_mode, "early_stop_eps": args.early_stop_eps, "triplane_relayout_in_step": not args.cache_triplane,
                        "step": ("enarf_prepare + enarf_triplane_pack + enarf_render_fwd" if args.unfused else
                                 "enarf_render_step_fwd (pre-march launch: re-layout + prepare + ray set-up; then the march)")},
             "roofline": {"bound": "hbm", "kernel": "enarf::render_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,

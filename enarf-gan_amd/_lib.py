@@ -9,8 +9,23 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# ENARF_LIB: A/B-test another build of the same ABI (tuning only)
-LIB_PATH = os.environ.get("ENARF_LIB") or os.path.join(_HERE, "csrc", "libenarf_hip.so")
+# The product loads the in-tree library and nothing else: no environment variable changes what runs.
+# Measurement tools that A/B a variant build of the same ABI call `use_variant(path)` explicitly, before the first load().
+LIB_PATH = os.path.join(_HERE, "csrc", "libenarf_hip.so")
+_variant = False
+
+
+def use_variant(path: str) -> None:
+    """Measurement only (bench.py --allow-variant, tools/): load another build of the same ABI instead of the in-tree one."""
+    global LIB_PATH, _variant
+    if _lib is not None:
+        raise EnarfHipError("use_variant() must be called before the library is loaded")
+    LIB_PATH, _variant = os.path.abspath(path), True
+
+
+def library_info() -> dict:
+    """What is (or will be) loaded: path and whether it is a variant build - bench.py prints this."""
+    return {"path": LIB_PATH, "variant": _variant}
 
 MAX_JOINTS = 32
 MAX_PARTS = 32

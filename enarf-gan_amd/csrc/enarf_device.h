@@ -218,7 +218,7 @@ struct Taps {
     int o00, o01, o10, o11;        // y*W + x of nw, ne, sw, se (clamped in-bounds)
     float w00, w01, w10, w11;      // weights, zeroed for out-of-bounds taps
 };
-__device__ __forceinline__ Taps make_taps(float x, float y, int H, int W) {
+__host__ __device__ __forceinline__ Taps make_taps(float x, float y, int H, int W) {
     Taps t;
     float ix, iy;
     {
@@ -237,6 +237,40 @@ __device__ __forceinline__ Taps make_taps(float x, float y, int H, int W) {
     t.o00 = cy0 * W + cx0; t.o01 = cy0 * W + cx1; t.o10 = cy1 * W + cx0; t.o11 = cy1 * W + cx1;
     // out-of-bounds taps weigh zero: zero the axis factor (all factors are >= 0, so the products are the same bits)
     const float zx0 = bx0 ? ax0 : 0.0f, zx1 = bx1 ? ax1 : 0.0f, zy0 = by0 ? ay0 : 0.0f, zy1 = by1 ? ay1 : 0.0f;
+    t.w00 = zx0 * zy0;
+    t.w01 = zx1 * zy0;
+    t.w10 = zx0 * zy1;
+    t.w11 = zx1 * zy1;
+    return t;
+}
+// The same taps for coordinates of a VALID (part, point) pair, i.e. |x| < 1 and |y| < 1 strictly (narf.py:201), with half
+// the range logic. For such a coordinate (x + 1) lies in [2^-24, 2] after rounding (1 - 2^-24 + 1 rounds up to 2), so
+//   ix = ((x + 1) W - 1) / 2 lies in [-0.5 + eps, W - 0.5],   x0 = floor(ix) in [-1, W - 1],   x1 = x0 + 1 in [0, W]:
+// x0 can only leave the plane at the low end and x1 only at the HIGH end - x1 == W (and y1 == H) does occur, for the
+// last half texel before +1. Its weight is zero, but its address is still formed: cy * W + W runs into the next row, and
+// (H) * W + x is a whole row past the plane - for the last feature plane of the last image that is up to W * 128 B
+// beyond the allocation. (A round-1 experiment dropped exactly these two upper clamps - "valid points are in range" -
+// and faulted intermittently at full frame size; this is why.) So: x0 needs max(., 0), x1 needs min(., W - 1), nothing
+// else. Coordinates outside (-1, 1) are NOT handled (the callers' lanes for invalid pairs are masked off before any
+// address is used); tests/host/taps_check.hip sweeps every float near +-1 against make_taps.
+__host__ __device__ __forceinline__ Taps make_taps_valid(float x, float y, int H, int W) {
+    Taps t;
+    float ix, iy;
+    {
+#pragma clang fp contract(off)
+        ix = ((x + 1.0f) * (float)W - 1.0f) / 2.0f;
+        iy = ((y + 1.0f) * (float)H - 1.0f) / 2.0f;
+    }
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+    const float ax1 = ix - fx, ax0 = (fx + 1.0f) - ix;
+    const float ay1 = iy - fy, ay0 = (fy + 1.0f) - iy;
+    const int cx0 = max(x0, 0), cx1 = min(x1, W - 1);
+    const int cy0 = max(y0, 0), cy1 = min(y1, H - 1);
+    const int r0 = cy0 * W, r1 = cy1 * W;
+    t.o00 = r0 + cx0; t.o01 = r0 + cx1; t.o10 = r1 + cx0; t.o11 = r1 + cx1;
+    const float zx0 = (x0 >= 0) ? ax0 : 0.0f, zx1 = (x1 < W) ? ax1 : 0.0f;
+    const float zy0 = (y0 >= 0) ? ay0 : 0.0f, zy1 = (y1 < H) ? ay1 : 0.0f;
     t.w00 = zx0 * zy0;
     t.w01 = zx1 * zy0;
     t.w10 = zx0 * zy1;

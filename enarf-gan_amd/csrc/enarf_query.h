@@ -13,8 +13,17 @@
 #ifndef ENARF_ROUND_PRIO
 #define ENARF_ROUND_PRIO 2
 #endif
-#ifndef ENARF_PLANE_SERIAL
-#define ENARF_PLANE_SERIAL 2
+// Work-skipping switches exist only in diagnostic variant builds (tools/build_variant.sh NAME -DENARF_DIAG_ABLATE=k:
+// 4 skips the MLP, 8 replaces the importance draw by a fixed grid); the product library is compiled with 0 and reads no
+// environment variable.
+#ifndef ENARF_DIAG_ABLATE
+#define ENARF_DIAG_ABLATE 0
+#endif
+#ifndef ENARF_DIAG_SCALAR_REDUCE      // A/B only: the round-1 scalar spelling of the tap reduction
+#define ENARF_DIAG_SCALAR_REDUCE 0
+#endif
+#ifndef ENARF_DIAG_GENERAL_TAPS       // A/B only: fully clamped make_taps in the gather rounds instead of make_taps_valid
+#define ENARF_DIAG_GENERAL_TAPS 0
 #endif
 
 namespace enarf {
@@ -51,7 +60,6 @@ struct QueryCtx {
     mutable unsigned long long tmr[8];
     mutable unsigned long long tmr_t;
 #endif
-    int ablate;              // diagnosis-only switches (ENARF_ABLATE), wave-uniform; 0 in production
     const float *mlp;        // LDS: fp32 weights of the MLP pack [PK_W1, PK_B1) (mode F32), else unused
     const short *mlp_h;      // LDS: bf16 section (modes BF16X3 / BF16) or fp16 section (F16X3), else unused
     const float *bias;       // LDS: 144 floats = pack[PK_B1, PK_F32_FLOATS): b1[64] b2[64] b3[16]
@@ -134,7 +142,12 @@ __device__ __forceinline__ void tap4u_issue(const char *__restrict__ base, unsig
     r.a0 = p00[0]; r.a1 = p00[1]; r.b0 = p01[0]; r.b1 = p01[1];
     r.c0 = p10[0]; r.c1 = p10[1]; r.d0 = p11[0]; r.d1 = p11[1];
 }
+// Channel pairs as 2-vectors: each step is one v_pk_mul_f32 / v_pk_fma_f32 with the tap weight broadcast by op_sel
+// (16 VALU per plane). Written with vector types on purpose: from the scalar form the SLP vectoriser pairs TAPS instead
+// of channels for one of the three planes and pays ~50 moves and scalar adds per round to assemble the operands.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void tap4u_reduce(const TapRegs &r, const Taps &t, float s[8]) {
+#if ENARF_DIAG_SCALAR_REDUCE
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         s[c] = r.a0[c] * t.w00;
@@ -146,6 +159,22 @@ __device__ __forceinline__ void tap4u_reduce(const TapRegs &r, const Taps &t, fl
         s[4 + c] += r.c1[c] * t.w10;
         s[4 + c] += r.d1[c] * t.w11;
     }
+#else
+    const f32x2 w00 = {t.w00, t.w00}, w01 = {t.w01, t.w01}, w10 = {t.w10, t.w10}, w11 = {t.w11, t.w11};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const f32x4 &a = h ? r.a1 : r.a0, &b = h ? r.b1 : r.b0, &c = h ? r.c1 : r.c0, &d = h ? r.d1 : r.d0;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            f32x2 v = f32x2{a[2 * q], a[2 * q + 1]} * w00;
+            v = __builtin_elementwise_fma(f32x2{b[2 * q], b[2 * q + 1]}, w01, v);
+            v = __builtin_elementwise_fma(f32x2{c[2 * q], c[2 * q + 1]}, w10, v);
+            v = __builtin_elementwise_fma(f32x2{d[2 * q], d[2 * q + 1]}, w11, v);
+            s[4 * h + 2 * q] = v[0];
+            s[4 * h + 2 * q + 1] = v[1];
+        }
+    }
+#endif
 }
 
 // acc[c] += weight * sum over planes xy, yz, zx of bilinear(feature plane, canonical)  (sampling.py:79-127)
@@ -511,8 +540,13 @@ __device__ __forceinline__ void query_tile(const QueryCtx &S, const int *cand_li
         // lane g owns plane g: xy, yz, zx (lane 3 repeats plane 0 and is ignored)
         const float qx = (g == 1) ? cy : (g == 2) ? cz : cx;
         const float qy = (g == 1) ? cz : (g == 2) ? cx : cy;
-        const Taps t = make_taps(qx, qy, S.H, S.W);   // fully clamped: every tap index is in-plane whatever the input
-#if ENARF_PLANE_SERIAL == 2
+        // the pair is valid: |canonical| < 1 strictly, the precondition of make_taps_valid (lanes without a pair compute
+        // garbage taps here and never use them: every load below sits behind `act`)
+#if ENARF_DIAG_GENERAL_TAPS
+        const Taps t = make_taps(qx, qy, S.H, S.W);
+#else
+        const Taps t = make_taps_valid(qx, qy, S.H, S.W);
+#endif
         // Pipelined round: the 4 mask taps and the 16 feature loads of planes 0 and 1 are issued back to back; the
         // part probability is formed while they are in flight; plane 2's loads go out as soon as plane 0 is reduced.
         // Two exposed memory latencies per round (the serial form below has five: the compiler splits the mask taps
@@ -570,74 +604,6 @@ __device__ __forceinline__ void query_tile(const QueryCtx &S, const int *cand_li
             TMR2(S, 6);
         }
         TMR(S, 3);
-#else
-        float sg = 1.0f;
-        if (act && g < 3 && !(S.ablate & 2)) {   // part probability plane g (sampling.py:43-48, :62)
-            const float *mp = S.mask + (size_t)(3 * k + g) * mplane;
-            float acc = mp[t.o00] * t.w00;
-            acc += mp[t.o01] * t.w01;
-            acc += mp[t.o10] * t.w10;
-            acc += mp[t.o11] * t.w11;
-            sg = sigmoidf_(acc);
-        }
-        const float w = (quad_bcast_f<0>(sg) * quad_bcast_f<1>(sg)) * quad_bcast_f<2>(sg);
-        TMR(S, 2);
-#if ENARF_PLANE_SERIAL == 1
-        // one plane's 8 loads in flight at a time: fewer VGPRs per wave, more waves per SIMD
-        float acc[8];
-        {
-            const Taps t0 = quad_bcast_taps<0>(t);
-            if (act && !(S.ablate & 1)) tap4u(featb, goff, t0, acc);
-            else {
-#pragma unroll
-                for (int c = 0; c < 8; ++c) acc[c] = 0.0f;
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        {
-            const Taps t1 = quad_bcast_taps<1>(t);
-            float s1[8];
-            if (act && !(S.ablate & 1)) {
-                tap4u(featb, goff + fplane_b, t1, s1);
-#pragma unroll
-                for (int c = 0; c < 8; ++c) acc[c] += s1[c];
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        {
-            const Taps t2 = quad_bcast_taps<2>(t);
-            float s2[8];
-            if (act && !(S.ablate & 1)) {
-                tap4u(featb, goff + 2u * fplane_b, t2, s2);
-#pragma unroll
-                for (int c = 0; c < 8; ++c) acc[c] += s2[c];
-            }
-        }
-        if (act) {
-#pragma unroll
-            for (int c = 0; c < 8; ++c) feat[c] += acc[c] * w;
-            wmax = fmaxf(wmax, w);
-            if (DBG && dbg.weight && g == 0) dbg.weight[(size_t)k * dbg.N + dbg.i] = w;
-        }
-#else
-        const Taps t0 = quad_bcast_taps<0>(t), t1 = quad_bcast_taps<1>(t), t2 = quad_bcast_taps<2>(t);
-        float s0[8], s1[8], s2[8];
-        if (act && !(S.ablate & 1)) {
-            tap4u(featb, goff, t0, s0);
-            tap4u(featb, goff + fplane_b, t1, s1);
-            tap4u(featb, goff + 2u * fplane_b, t2, s2);
-        } else {
-#pragma unroll
-            for (int c = 0; c < 8; ++c) s0[c] = s1[c] = s2[c] = 0.0f;
-        }
-        if (act) {
-#pragma unroll
-            for (int c = 0; c < 8; ++c) feat[c] += ((s0[c] + s1[c]) + s2[c]) * w;
-            wmax = fmaxf(wmax, w);
-            if (DBG && dbg.weight && g == 0) dbg.weight[(size_t)k * dbg.N + dbg.i] = w;
-        }
-#endif
-#endif
         n_pairs += (unsigned)(__popcll(bal) >> 2);
         if (n_rounds) *n_rounds += 1;
         TMR(S, 3);
@@ -646,7 +612,7 @@ __device__ __forceinline__ void query_tile(const QueryCtx &S, const int *cand_li
 #if ENARF_ROUND_PRIO
     __builtin_amdgcn_s_setprio(0);
 #endif
-    ran = (__ballot(b != 0) != 0) && !(S.ablate & 4);
+    ran = (__ballot(b != 0) != 0) && !(ENARF_DIAG_ABLATE & 4);
     if (ran) {
         n_tiles += 1;
         float x[8];

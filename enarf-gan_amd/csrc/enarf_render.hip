@@ -2,7 +2,6 @@
 // gfx950 only. See include/enarf_hip.h for the contract and DESIGN.md for the kernel design.
 #include "enarf_march.h"
 #include "enarf_host.h"
-#include <cstdlib>
 
 #ifndef ENARF_S2_PRIO
 #define ENARF_S2_PRIO 3
@@ -188,7 +187,6 @@ __global__ __launch_bounds__(256) void query_kernel(const enarf_query_args a, in
     S.feat = a.feat_cl + (size_t)b * a.feat_batch_stride;
     S.mask = a.mask_planes + (size_t)b * a.mask_batch_stride;
     S.H = a.H; S.W = a.W; S.P = a.P; S.mult_w = a.multiply_density_with_weight;
-    S.ablate = 0;
     int *l_cand = reinterpret_cast<int *>(scratch + 8);
     if (tid < a.P) l_cand[tid] = tid;                 // every part is a candidate for a free point cloud
     __syncthreads();
@@ -299,8 +297,7 @@ __device__ __forceinline__ bool ray_hits_part(const float *F, float dx, float dy
 // =================================================================================================
 // ray set-up pre-pass: depth range, candidate parts and the compacted list of rays to march
 // =================================================================================================
-// workspace layout: 64-byte header: [0] unused, [1] number of live rays, [2..9] the 8 per-XCD queue heads (u32); then one 16-byte record
-// per ray {depth_min, depth_max, candidate part bits, valid}; then the list of live ray ids (u32).
+// workspace layout: see enarf_march.h (two queue headers, one 32-byte RayRec per ray, kQueues x kClasses ray lists).
 // decide_frustrum_range (rendering.py:10-79) for every ray, 4 adjacent lanes per ray: the quad splits the parts
 // for the conservative slab tests and the 32 range-test depths (8 each) for the exact cube tests. Rays the
 // reference drops (batch 1, no cube hit: rendering.py:107-110, :337-350) get their zero outputs here and never
@@ -528,7 +525,7 @@ static_assert(SC_QUEUE + kQueueLdsInts <= SC_BINS && SC_BINS + kMaxSamples + 8 <
 // SPL = samples per lane in the lane = sample stages: 1 for Nc, Nf <= 64, 2 up to 128 (each wave then loops over two
 // 16-sample tiles per pass)
 template <int MODE, int SPL>
-__global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kernel(const enarf_render_args a, int ablate) {
+__global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kernel(const enarf_render_args a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // Persistent workgroups: each marches one ray at a time, taken off the (band, cost class) lists the set-up pass
@@ -553,7 +550,6 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
     S.feat = a.feat_cl + (size_t)b * a.feat_batch_stride;
     S.mask = a.mask_planes + (size_t)b * a.mask_batch_stride;
     S.H = a.H; S.W = a.W; S.P = P; S.mult_w = a.multiply_density_with_weight;
-    S.ablate = ablate;
     float *l_btab = scratch + SC_BTAB;
     int *l_cand = reinterpret_cast<int *>(scratch + SC_CAND) + wave * 32;
     float *l_ch = scratch + SC_CH, *l_cwmax = scratch + SC_CWMAX, *l_fh = scratch + SC_FH, *l_fwmax = scratch + SC_FWMAX;
@@ -636,7 +632,7 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
         float usort[SPL];
 #pragma unroll
         for (int s = 0; s < SPL; ++s) usort[s] = 0.0f;
-        if (wave == spare_wave && !a.bins && !(ablate & 8)) {
+        if (wave == spare_wave && !a.bins && !(ENARF_DIAG_ABLATE & 8)) {
             float esum[SPL];
             uint32_t r1_first = 0;
 #pragma unroll
@@ -699,7 +695,7 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
                 ws[s] = (e < Nc) ? (fmaxf(wl[s], wgt[s]) + fmaxf(wgt[s], wr[s])) / 2.0f + 0.01f : 0.0f;
             }
             TMR4(S, 1);
-            if (ablate & 8) {
+            if (ENARF_DIAG_ABLATE & 8) {
 #pragma unroll
                 for (int s = 0; s < SPL; ++s) bin[s] = (float)(64 * s + lane) / (float)Nf;
             } else if (a.bins) {
@@ -1007,15 +1003,12 @@ static int launch_render(const enarf_render_args &a, hipStream_t st, bool with_s
     const int num_cus = device_cus();
     if (num_cus <= 0) return host::fail((int)hipGetLastError(), "enarf_render_fwd: cannot query the device");
     const long long total = (long long)a.B * a.n;
-    const char *wp = getenv("ENARF_WGS_PER_CU");      // tuning only
-    const int per_cu = (wp && atoi(wp) > 0) ? atoi(wp) : ENARF_RENDER_WAVES_PER_SIMD;
-    long long wgs = (long long)num_cus * per_cu;
+    long long wgs = (long long)num_cus * ENARF_RENDER_WAVES_PER_SIMD;
     if (wgs > total) wgs = total;
     const size_t lds = (size_t)lds_total_floats<MODE>(a.P) * 4;
-    const char *ab = getenv("ENARF_ABLATE");      // diagnosis only: 1 skip feature gathers, 2 skip mask planes, 4 skip MLP
     if (with_setup)
         if (int rc = launch_ray_setup(a, st)) return rc;
-    hipLaunchKernelGGL((render_kernel<MODE, SPL>), dim3((unsigned)wgs), dim3(256), lds, st, a, ab ? atoi(ab) : 0);
+    hipLaunchKernelGGL((render_kernel<MODE, SPL>), dim3((unsigned)wgs), dim3(256), lds, st, a);
     return host::check_launch("enarf_render_fwd");
 }
 

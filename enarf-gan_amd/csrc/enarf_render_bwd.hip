@@ -13,7 +13,6 @@
 //       gradient planes with float atomics
 #include "enarf_march.h"
 #include "enarf_host.h"
-#include <cstdlib>
 
 #ifndef ENARF_BWD_ABLATE
 #define ENARF_BWD_ABLATE 0      // diagnosis builds only: 1 no feature atomics, 2 no mask atomics, 4 no scatter pass, 8 no row export
@@ -314,7 +313,7 @@ __global__ __launch_bounds__(256, kBwdWavesPerSimd) void render_bwd_kernel(const
     int b = -1;
     QueryCtx S;
     S.mlp = l_w; S.mlp_h = nullptr; S.bias = l_bias; S.parts = l_parts; S.canon = l_canon;
-    S.H = a.H; S.W = a.W; S.P = P; S.mult_w = 0; S.ablate = 0;
+    S.H = a.H; S.W = a.W; S.P = P; S.mult_w = 0;
     int *l_cand = reinterpret_cast<int *>(scratch + SB_CAND) + wave * 32;
     float *l_fh = scratch + SB_FH, *l_dz3 = scratch + SB_DZ3;
     float *ttile = scratch + kBwdScratchFloats + wave * kTTile;     // this wave's atomic-transpose tile
@@ -442,7 +441,7 @@ __global__ __launch_bounds__(256, kBwdWavesPerSimd) void query_bwd_kernel(const 
     float *l_canon = l_parts + P * kLdsPartStride, *scratch = l_canon + P * kLdsCanonStride;
     QueryCtx S;
     S.mlp = l_w; S.mlp_h = nullptr; S.bias = l_bias; S.parts = l_parts; S.canon = l_canon;
-    S.H = a.H; S.W = a.W; S.P = P; S.mult_w = 0; S.ablate = 0;
+    S.H = a.H; S.W = a.W; S.P = P; S.mult_w = 0;
     S.feat = a.feat_cl + (size_t)b * a.feat_batch_stride;
     S.mask = a.mask_planes + (size_t)b * a.mask_batch_stride;
     int *l_cand = reinterpret_cast<int *>(scratch + SB_CAND);

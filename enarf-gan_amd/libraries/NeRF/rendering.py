@@ -29,7 +29,7 @@ _MLP_LEAVES = ("conv.weight", "conv.modulation.weight", "conv.modulation.bias", 
 
 class _RenderFunction(torch.autograd.Function):
     """Differentiable wrapper of the fused march: forward = enarf_prepare (MLP pack) + enarf_triplane_pack +
-    enarf_render_fwd, backward = enarf_render_bwd + library GEMMs for dW' + enarf_prepare_bwd + un-pack.
+    enarf_render_fwd, backward = enarf_render_bwd + enarf_weight_grad (dW') + enarf_prepare_bwd + un-pack.
     Differentiable inputs: the tri-plane, z_rend and the 12 StyledMLP tensors (as in the reference, not the pose and
     not the importance samples)."""
 

@@ -221,8 +221,7 @@ class TriPlaneNARF(nn.Module):
         return self._mlp_pack_from(z_rend, self.mlp.as_dict())
 
     def _mlp_pack_from(self, z_rend: torch.Tensor, mlp: Dict[str, torch.Tensor]) -> torch.Tensor:
-        _, pack = ops_prepare_mlp_only(self, z_rend, mlp)
-        return pack
+        return ops.prepare_mlp(z_rend, mlp)
 
     # ---- the reference's entry points -------------------------------------------------------------------------------
     def forward(self, batchsize, sampled_img_coord, pose_to_camera, inv_intrinsics, z, z_rend, bone_length,
@@ -370,31 +369,3 @@ class _QueryFunction(torch.autograd.Function):
             grads += [pg[f"layers.{i}.conv.weight"], pg[f"layers.{i}.conv.modulation.weight"],
                       pg[f"layers.{i}.conv.modulation.bias"], db[i].reshape(params[4 * i + 3].shape)]
         return (None, grad_tri, dz) + tuple(grads)
-
-
-def ops_prepare_mlp_only(model: TriPlaneNARF, z_rend: torch.Tensor, sd: Optional[Dict[str, torch.Tensor]] = None):
-    """enarf_prepare with parts == NULL: only the per-image modulated MLP pack."""
-    import ctypes as C
-    from .. import _lib
-    lib = _lib.load()
-    z = z_rend.detach().float().contiguous()
-    B = z.shape[0]
-    a = _lib.PrepareArgs()
-    a.B, a.num_joints, a.origin_location, a.style_dim = B, model.num_joints, _lib.ORIGIN[model.origin_location], z.shape[1]
-    a.coordinate_scale = float(model.coordinate_scale)
-    for j in range(model.num_joints):
-        a.parents[j] = int(model.parent_id[j])
-    a.z_rend = z.data_ptr()
-    keep = []
-    if sd is None:
-        sd = model.mlp.as_dict()
-    for i in range(3):
-        ts = [sd[f"layers.{i}.conv.weight"], sd[f"layers.{i}.conv.modulation.weight"],
-              sd[f"layers.{i}.conv.modulation.bias"], sd[f"layers.{i}.bias"]]
-        ts = [t.detach().float().contiguous() for t in ts]
-        keep += ts
-        a.conv_weight[i], a.mod_weight[i], a.mod_bias[i], a.bias[i] = [t.data_ptr() for t in ts]
-    pack = torch.empty(B, ops.mlp_pack_bytes(), dtype=torch.uint8, device=z.device)
-    a.parts, a.mlp_pack = None, pack.data_ptr()
-    _lib.check(lib.enarf_prepare(C.byref(a), torch.cuda.current_stream(z.device).cuda_stream), "enarf_prepare")
-    return None, pack

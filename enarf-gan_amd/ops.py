@@ -19,6 +19,33 @@ def _p(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
+def _first_cuda_tensor(args, kwargs) -> Optional[torch.Tensor]:
+    for v in list(args) + list(kwargs.values()):
+        if isinstance(v, torch.Tensor) and v.is_cuda:
+            return v
+        if isinstance(v, dict):
+            for w in v.values():
+                if isinstance(w, torch.Tensor) and w.is_cuda:
+                    return w
+    return None
+
+
+def _on_tensor_device(fn):
+    """The library launches on the stream it is handed, and a HIP stream belongs to one device: make the device of the
+    call's first device tensor current for the duration of the call (a process that drives several GPUs may have another
+    one current)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*args, **kwargs):
+        t = _first_cuda_tensor(args, kwargs)
+        if t is None or t.device.index == torch.cuda.current_device():
+            return fn(*args, **kwargs)
+        with torch.cuda.device(t.device):
+            return fn(*args, **kwargs)
+    return wrapped
+
+
 def _stream(dev: torch.device) -> int:
     return torch.cuda.current_stream(dev).cuda_stream
 
@@ -40,6 +67,7 @@ def num_parts(num_joints: int, origin_location: str) -> int:
 
 
 # ---------------------------------------------------------------------------------------- a1 operator
+@_on_tensor_device
 def triplane_sample_fwd(inp: torch.Tensor, grid: torch.Tensor, mode: int = 0, padding_mode: int = 0,
                         align_corners: bool = False, use_workspace: bool = True) -> torch.Tensor:
     """input (B,3C,H,W), grid (B,h,w,3) -> (B,C,h,w); cuda_extension/TriplaneSampler.cpp:15-24."""
@@ -64,6 +92,7 @@ def triplane_sample_fwd(inp: torch.Tensor, grid: torch.Tensor, mode: int = 0, pa
     return out
 
 
+@_on_tensor_device
 def triplane_sample_bwd(grad_out: torch.Tensor, inp: torch.Tensor, grid: torch.Tensor, mode: int, padding_mode: int,
                         align_corners: bool, need_input: bool, need_grid: bool, use_workspace: bool = True
                         ) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
@@ -88,6 +117,7 @@ def triplane_sample_bwd(grad_out: torch.Tensor, inp: torch.Tensor, grid: torch.T
 
 
 # ---------------------------------------------------------------------------------------- re-layout
+@_on_tensor_device
 def triplane_pack(tri_nchw: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """(B, 96+3P, H, W) NCHW -> feature planes channel-last (B, 3, H, W, 32)."""
     lib = _lib.load()
@@ -100,6 +130,7 @@ def triplane_pack(tri_nchw: torch.Tensor, out: Optional[torch.Tensor] = None) ->
     return out
 
 
+@_on_tensor_device
 def triplane_unpack_add(grad_feat_cl: torch.Tensor, grad_tri_nchw: torch.Tensor) -> torch.Tensor:
     """grad_tri[:, :96] += channel-last gradient (B, 3, H, W, 32) (the inverse re-layout)."""
     lib = _lib.load()
@@ -110,6 +141,7 @@ def triplane_unpack_add(grad_feat_cl: torch.Tensor, grad_tri_nchw: torch.Tensor)
     return grad_tri_nchw
 
 
+@_on_tensor_device
 def triplane_warp_fwd(src_cl: torch.Tensor, flow: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Deformation-field producer: src_cl (1|-,3,H,W,32) channel-last constant planes, flow (B,6,H,W) -> (B,3,H,W,32)."""
     lib = _lib.load()
@@ -124,6 +156,7 @@ def triplane_warp_fwd(src_cl: torch.Tensor, flow: torch.Tensor, out: Optional[to
     return out
 
 
+@_on_tensor_device
 def triplane_warp_bwd(g_out_cl: torch.Tensor, src_cl: torch.Tensor, flow: torch.Tensor, need_src: bool = True,
                       need_flow: bool = True):
     """-> (g_src_cl (3,H,W,32) or None, g_flow (B,6,H,W) or None)."""
@@ -179,6 +212,7 @@ def _prepare_args(pose_to_camera, bone_length, canonical_bone_length, z_rend, ml
     return a, keep, parts_out, pack_out
 
 
+@_on_tensor_device
 def prepare(pose_to_camera: torch.Tensor, bone_length: torch.Tensor, canonical_bone_length: torch.Tensor,
             z_rend: torch.Tensor, mlp: Dict[str, torch.Tensor], parents: Sequence[int], origin_location: str,
             coordinate_scale: float, parts_out: Optional[torch.Tensor] = None,
@@ -192,6 +226,34 @@ def prepare(pose_to_camera: torch.Tensor, bone_length: torch.Tensor, canonical_b
     return parts_out, pack_out
 
 
+@_on_tensor_device
+def prepare_mlp(z_rend: torch.Tensor, mlp: Dict[str, torch.Tensor], pack_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """enarf_prepare with parts == NULL: only the per-image modulated, demodulated MLP pack (B, pack_bytes) uint8."""
+    lib = _lib.load()
+    z = _dev_f32(z_rend.detach(), "z_rend")
+    B = z.shape[0]
+    a = _lib.PrepareArgs()
+    a.B, a.num_joints, a.origin_location, a.style_dim = B, 2, ORIGIN["center_fixed"], z.shape[1]   # joints unused without parts
+    a.coordinate_scale = 1.0
+    a.parents[0], a.parents[1] = -1, 0
+    a.z_rend = _p(z)
+    keep = [z]
+    dims = [(FEAT_DIM, 64), (64, 64), (64, 4)]
+    for i, (cin, cout) in enumerate(dims):
+        ts = [_dev_f32(mlp[f"layers.{i}.{leaf}"].detach(), leaf) for leaf in
+              ("conv.weight", "conv.modulation.weight", "conv.modulation.bias", "bias")]
+        if ts[0].numel() != cin * cout or ts[1].shape != (cin, z.shape[1]) or ts[2].numel() != cin or ts[3].numel() != cout:
+            raise ValueError(f"StyledMLP layer {i}: unexpected parameter shapes {[tuple(t.shape) for t in ts]}")
+        keep += ts
+        a.conv_weight[i], a.mod_weight[i], a.mod_bias[i], a.bias[i] = [_p(t) for t in ts]
+    if pack_out is None:
+        pack_out = torch.empty(B, mlp_pack_bytes(), dtype=torch.uint8, device=z.device)
+    a.parts, a.mlp_pack = None, _p(pack_out)
+    _lib.check(lib.enarf_prepare(C.byref(a), _stream(z.device)), "enarf_prepare")
+    return pack_out
+
+
+@_on_tensor_device
 def mlp_unpack(pack_one_image: torch.Tensor):
     """Dense (W1 (64,32), W2 (64,64), W3 (4,64), b1, b2, b3) from one image's pack (tests / interop)."""
     lib = _lib.load()
@@ -217,6 +279,7 @@ def _plane_strides(tri_nchw: torch.Tensor, feat_cl: torch.Tensor, B: int):
 
 
 # ---------------------------------------------------------------------------------------- a9 query
+@_on_tensor_device
 def query_fwd(points: Optional[torch.Tensor], parts: torch.Tensor, canonical_pose: torch.Tensor, tri_nchw: torch.Tensor,
               feat_cl: torch.Tensor, mlp_pack: torch.Tensor, mlp_mode: str = "f32",
               multiply_density_with_weight: bool = False, need_color: bool = True, need_valid: bool = False,
@@ -320,6 +383,7 @@ class RenderOutputs:
     __slots__ = ("color", "mask", "disparity", "fine_weights", "fine_depth", "taps", "counters")
 
 
+@_on_tensor_device
 def render_fwd(image_coord: torch.Tensor, inv_intrinsics: torch.Tensor, parts: torch.Tensor,
                canonical_pose: torch.Tensor, tri_nchw: torch.Tensor, feat_cl: torch.Tensor, mlp_pack: torch.Tensor,
                Nc: int, Nf: int, render_scale: float = 1.0, bins: Optional[torch.Tensor] = None, seed: int = 0,
@@ -428,6 +492,12 @@ class RenderStep:
         self._keep = k1 + k2
 
     def run(self, phases: int = STEP_ALL) -> RenderOutputs:
+        if self.tri.device.index != torch.cuda.current_device():
+            with torch.cuda.device(self.tri.device):
+                return self._run(phases)
+        return self._run(phases)
+
+    def _run(self, phases: int) -> RenderOutputs:
         t = self.tri
 
         def call():
@@ -451,6 +521,7 @@ def render_step_fwd(*args, **kw) -> RenderOutputs:
 
 
 # ---------------------------------------------------------------------------------------- backward
+@_on_tensor_device
 def render_bwd(image_coord, inv_intrinsics, parts, canonical_pose, tri_nchw, feat_cl, mlp_pack, Nf, bins,
                g_color, g_mask, g_disparity=None, render_scale: float = 1.0, drop_invalid_rays: Optional[bool] = None,
                feat_grad_channel_last: bool = False):
@@ -459,7 +530,7 @@ def render_bwd(image_coord, inv_intrinsics, parts, canonical_pose, tri_nchw, fea
     Returns (grad_tri (same batch as tri_nchw: 1 for a shared tri-plane), dW [3 x (B,out,in)], db [3 x (out,)]).
     feat_grad_channel_last: the feature-plane gradient stays channel-last (same shape as feat_cl) and is returned as a
     fourth value instead of being folded into grad_tri[:, :96] (for producers that emit channel-last planes).
-    The weight gradients are formed from the kernel's per-tile rows by enarf_weight_grad (MFMA split-K, no host sync)."""
+    The weight gradients are formed from the kernel's per-tile rows by enarf_weight_grad (own MFMA split-K kernels, no library GEMM, no host sync)."""
     lib = _lib.load()
     coord = _dev_f32(image_coord, "image_coord")
     B, n = coord.shape[0], coord.shape[-1]
@@ -531,6 +602,7 @@ def _weight_grad(bufs, blocks, B: int, rows: int, dev: torch.device):
     return dW, [t.sum(dim=0) for t in dbb]
 
 
+@_on_tensor_device
 def query_bwd(points, parts, canonical_pose, tri_nchw, feat_cl, mlp_pack, g_density, g_color):
     """Backward of query_fwd w.r.t. the tri-plane and the per-image demodulated MLP weights / biases.
 
@@ -569,6 +641,7 @@ def query_bwd(points, parts, canonical_pose, tri_nchw, feat_cl, mlp_pack, g_dens
     return grad_tri, dW, db
 
 
+@_on_tensor_device
 def prepare_bwd(z_rend: torch.Tensor, mlp: Dict[str, torch.Tensor], dW):
     """dW' (3 x (B,out,in)) -> gradients of conv.weight, modulation.weight, modulation.bias (summed over the batch,
     in the parameters' own shapes) and of z_rend (B, style_dim)."""

@@ -173,7 +173,7 @@ int enarf_query_fwd(const enarf_query_args *args, enarf_stream_t stream);
  * --------------------------------------------------------------------------------------------- */
 typedef struct {
     int B, n;                             /* images, rays per image */
-    int P, Nc, Nf;                        /* parts, coarse / fine samples per ray (each <= 64) */
+    int P, Nc, Nf;                        /* parts, coarse / fine samples per ray (2 <= Nc, Nf <= 128) */
     int H, W;
     int mlp_mode;
     int multiply_density_with_weight;
@@ -242,7 +242,7 @@ int enarf_render_step_fwd(const enarf_prepare_args *prep, const float *tri_nchw,
  * only (the importance samples are not differentiable) and not into poses.
  *   enarf_render_bwd   d loss / d tri-plane (atomically accumulated into caller-zeroed buffers) and, per valid
  *                      16-sample tile, the rows (x, h1, h2, dz1, dz2, dz3) from which the caller forms the weight
- *                      gradients dW'_l = dZ_l^T H_{l-1} with a library GEMM, per image.
+ *                      gradients dW'_l = dZ_l^T H_{l-1} with enarf_weight_grad, per image.
  *   enarf_prepare_bwd  d loss / d (conv.weight, modulation.weight, modulation.bias, z_rend) from dW' (the backward of
  *                      ModulatedConv1d's modulate + F.normalize), per image; the caller sums the shared parameters.
  *   enarf_triplane_unpack_add   grad_tri[:, :96] += channel-last gradient (inverse of enarf_triplane_pack).

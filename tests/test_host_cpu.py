@@ -76,6 +76,37 @@ def test_argument_validation_needs_no_device():
     assert lib.enarf_triplane_sample_workspace_bytes(2, 5, 256, 256) == 0
 
 
+def test_tap_offsets_stay_inside_the_plane(tmp_path):
+    """The bilinear tap index math of csrc/enarf_device.h, compiled for the HOST and swept over every float near the
+    faces of the unit cube (tests/host/taps_check.hip): make_taps never leaves the plane for any input, and the light
+    make_taps_valid used for valid pairs equals it for every |c| < 1 - including the last half texel before +1, where
+    x1 == W / y1 == H (the address a round-1 experiment left unclamped)."""
+    import subprocess
+    exe = str(tmp_path / "taps_check")
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "include"),
+                    "-I", os.path.join(ROOT, "enarf-gan_amd", "csrc"), os.path.join(ROOT, "tests", "host", "taps_check.hip"),
+                    "-o", exe], check=True, capture_output=True)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.startswith("ok "), r.stdout + r.stderr
+    assert int(r.stdout.split()[1]) > 100000
+
+
+def test_product_reads_no_environment_switches():
+    """A renderer whose output changes with an environment variable is a defect: the product sources
+    read none, and the library path can only be changed by an explicit use_variant() call from a measurement tool."""
+    import glob
+    from enarf_gan_amd import _lib
+    pkg = os.path.join(ROOT, "enarf-gan_amd")
+    for f in glob.glob(os.path.join(pkg, "csrc", "*.h*")):
+        assert "getenv" not in open(f).read(), f
+    for f in glob.glob(os.path.join(pkg, "**", "*.py"), recursive=True):
+        if os.path.basename(f) == "build.py":
+            continue          # HIPCC (compiler path) only
+        src = open(f).read()
+        assert "os.environ" not in src and "getenv" not in src, f
+    assert _lib.library_info() == {"path": os.path.join(pkg, "csrc", "libenarf_hip.so"), "variant": False}
+
+
 def test_no_cpu_fallback():
     from enarf_gan_amd import _lib, ops
     with pytest.raises(_lib.EnarfHipError):

@@ -9,6 +9,19 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 from enarf_gan_amd import ops, synth  # noqa: E402
+
+def _maybe_variant():
+    """tools only: ENARF_VARIANT=<name> loads variants/libenarf_<name>.so (tools/build_variant.sh) instead of the in-tree build"""
+    import os
+    v = os.environ.get("ENARF_VARIANT")
+    if v:
+        from enarf_gan_amd import _lib
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        _lib.use_variant(v if os.path.sep in v else os.path.join(root, "variants", f"libenarf_{v}.so"))
+        print("variant library:", _lib.library_info()["path"], flush=True)
+
+
+_maybe_variant()
 from oracle import enarf_oracle as O  # noqa: E402  (canonical buffers of the synthetic scene only)
 
 S, B, Nc, Nf = int(os.environ.get("SIZE", 128)), int(os.environ.get("BATCH", 1)), 48, 64

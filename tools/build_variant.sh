@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/build_variant.sh NAME [-DFLAG=V ...]: a second build of the same ABI under variants/libenarf_NAME.so
-# (git-ignored; used through ENARF_LIB for A/B runs and the phase-timer diagnostic build)
+# (git-ignored; used through bench.py --allow-variant --variant PATH / ENARF_VARIANT=NAME of the tools for A/B runs and the phase-timer diagnostic build)
 set -e
 name=$1; shift
 root=$(cd "$(dirname "$0")/.." && pwd)

@@ -4,5 +4,5 @@
 ulimit -c 0
 python bench.py --no-cpu-baseline --steps 300 $BENCH_ARGS | python tools/exline.py base
 for n in "$@"; do
-  ENARF_LIB=$GRAFT_REPO_ROOT/variants/libenarf_$n.so timeout -k 10 120 python bench.py --no-cpu-baseline --steps 300 $BENCH_ARGS | python tools/exline.py $n || exit 1
+  timeout -k 10 120 python bench.py --no-cpu-baseline --steps 300 --allow-variant --variant variants/libenarf_$n.so $BENCH_ARGS | python tools/exline.py $n || exit 1
 done

@@ -1,9 +1,22 @@
-"""Phase breakdown of the march from a -DENARF_TIMERS=1 build (ENARF_LIB=variants/libenarf_timers.so): per-wave
+"""Phase breakdown of the march from a -DENARF_TIMERS=1 build (tools/build_variant.sh timers -DENARF_TIMERS=1; ENARF_VARIANT=timers): per-wave
 cycle sums per phase, printed as fractions of the summed wave time."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from enarf_gan_amd import ops, synth
+
+def _maybe_variant():
+    """tools only: ENARF_VARIANT=<name> loads variants/libenarf_<name>.so (tools/build_variant.sh) instead of the in-tree build"""
+    import os
+    v = os.environ.get("ENARF_VARIANT")
+    if v:
+        from enarf_gan_amd import _lib
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        _lib.use_variant(v if os.path.sep in v else os.path.join(root, "variants", f"libenarf_{v}.so"))
+        print("variant library:", _lib.library_info()["path"], flush=True)
+
+
+_maybe_variant()
 from oracle import enarf_oracle as O
 
 S, Nc, Nf = 128, 48, 64
