@@ -22,8 +22,11 @@
 #ifndef ENARF_DIAG_SCALAR_REDUCE      // A/B only: the round-1 scalar spelling of the tap reduction
 #define ENARF_DIAG_SCALAR_REDUCE 0
 #endif
-#ifndef ENARF_DIAG_GENERAL_TAPS       // A/B only: fully clamped make_taps in the gather rounds instead of make_taps_valid
-#define ENARF_DIAG_GENERAL_TAPS 0
+#ifndef ENARF_DIAG_GENERAL_TAPS       // 1: fully clamped make_taps in the gather rounds; 0: make_taps_valid
+#define ENARF_DIAG_GENERAL_TAPS 1
+#endif
+#ifndef ENARF_DIAG_TAPCHECK           // diagnosis only: range-check what make_taps_valid would address, march with make_taps
+#define ENARF_DIAG_TAPCHECK 0
 #endif
 
 namespace enarf {
@@ -69,6 +72,10 @@ struct QueryCtx {
     const float *mask;       // global: this image's part-probability planes [P*3][H][W]
     int H, W, P;
     int mult_w;              // multiply_density_with_triplane_wieght
+#if ENARF_DIAG_TAPCHECK
+    unsigned long long *diag;   // counters[5] violations, [6] first: rid | k << 32 | lane << 40 | kind << 48, [7] qx, qy bits
+    unsigned diag_rid;
+#endif
 };
 
 struct QueryDbg {            // optional taps of the point-cloud kernel
@@ -200,51 +207,76 @@ __device__ __forceinline__ f32x4 act4(f32x4 v) {
     return r;
 }
 
-// exact fp32: v_mfma_f32_16x16x4_f32, 112 MFMAs per tile
-__device__ __forceinline__ f32x4 mlp_tile_f32(const float *__restrict__ Wp, const float *__restrict__ Bp, const float x[8], int lane) {
-    const int g = lane >> 4;
-    f32x4 a1[4], a2[4];
+// ---- fp32 MFMA blocks (v_mfma_f32_16x16x4_f32), accumulate in place -------------------------------------------------------
+// Same rule as the split-precision MLP below (see there): every chained MFMA is issued from an asm block with tied
+// accumulators, independent chains interleaved, a trailing s_nop for the last write -> VALU read distance (8 passes + 3).
+// Summation order per output element = ascending k, as before: the results are bitwise those of an fmaf chain.
+#define ENARF_M32(d, a, b) "v_mfma_f32_16x16x4_f32 %" #d ", %" #a ", %" #b ", %" #d "\n\t"
+#define ENARF_M32_TAIL "s_nop 7\n\ts_nop 4"
+// c[i] += sum_t a[i][t] * b[t], i < 4, t < 4 (t outer: four independent chains interleaved)
+__device__ __forceinline__ void mfma32_acc4x4(f32x4 c[4], const float a[4][4], const float b[4]) {
+    asm volatile("s_nop 1\n\t"
+                 ENARF_M32(0, 4, 20) ENARF_M32(1, 8, 20) ENARF_M32(2, 12, 20) ENARF_M32(3, 16, 20)
+                 ENARF_M32(0, 5, 21) ENARF_M32(1, 9, 21) ENARF_M32(2, 13, 21) ENARF_M32(3, 17, 21)
+                 ENARF_M32(0, 6, 22) ENARF_M32(1, 10, 22) ENARF_M32(2, 14, 22) ENARF_M32(3, 18, 22)
+                 ENARF_M32(0, 7, 23) ENARF_M32(1, 11, 23) ENARF_M32(2, 15, 23) ENARF_M32(3, 19, 23)
+                 ENARF_M32_TAIL
+                 : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3])
+                 : "v"(a[0][0]), "v"(a[0][1]), "v"(a[0][2]), "v"(a[0][3]), "v"(a[1][0]), "v"(a[1][1]), "v"(a[1][2]), "v"(a[1][3]),
+                   "v"(a[2][0]), "v"(a[2][1]), "v"(a[2][2]), "v"(a[2][3]), "v"(a[3][0]), "v"(a[3][1]), "v"(a[3][2]), "v"(a[3][3]),
+                   "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]));
+}
+// c[i] += sum_t a[i][t] * b[t], i < 2, t < 8
+__device__ __forceinline__ void mfma32_acc2x8(f32x4 &c0, f32x4 &c1, const float a[2][8], const float b[8]) {
+    asm volatile("s_nop 1\n\t"
+                 ENARF_M32(0, 2, 18) ENARF_M32(1, 10, 18) ENARF_M32(0, 3, 19) ENARF_M32(1, 11, 19)
+                 ENARF_M32(0, 4, 20) ENARF_M32(1, 12, 20) ENARF_M32(0, 5, 21) ENARF_M32(1, 13, 21)
+                 ENARF_M32(0, 6, 22) ENARF_M32(1, 14, 22) ENARF_M32(0, 7, 23) ENARF_M32(1, 15, 23)
+                 ENARF_M32(0, 8, 24) ENARF_M32(1, 16, 24) ENARF_M32(0, 9, 25) ENARF_M32(1, 17, 25)
+                 ENARF_M32_TAIL
+                 : "+v"(c0), "+v"(c1)
+                 : "v"(a[0][0]), "v"(a[0][1]), "v"(a[0][2]), "v"(a[0][3]), "v"(a[0][4]), "v"(a[0][5]), "v"(a[0][6]), "v"(a[0][7]),
+                   "v"(a[1][0]), "v"(a[1][1]), "v"(a[1][2]), "v"(a[1][3]), "v"(a[1][4]), "v"(a[1][5]), "v"(a[1][6]), "v"(a[1][7]),
+                   "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7]));
+}
+// c += sum_t a[t] * b[t], t < 8: one dependent in-place chain
+__device__ __forceinline__ void mfma32_acc1x8(f32x4 &c, const float a[8], const float b[8]) {
+    asm volatile("s_nop 1\n\t"
+                 ENARF_M32(0, 1, 9) ENARF_M32(0, 2, 10) ENARF_M32(0, 3, 11) ENARF_M32(0, 4, 12)
+                 ENARF_M32(0, 5, 13) ENARF_M32(0, 6, 14) ENARF_M32(0, 7, 15) ENARF_M32(0, 8, 16)
+                 ENARF_M32_TAIL
+                 : "+v"(c)
+                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]),
+                   "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7]));
+}
+// c[i] = a[i] * b (one K = 4 step into zeroed accumulators), i < 4
+__device__ __forceinline__ void mfma32_set4x1(f32x4 c[4], const float a[4], float b) {
 #pragma unroll
-    for (int ob = 0; ob < 4; ++ob) a1[ob] = *reinterpret_cast<const f32x4 *>(Bp + 16 * ob + 4 * g);
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-#pragma unroll
-        for (int ob = 0; ob < 4; ++ob)
-            a1[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wp[PK_W1 + (ob * 8 + s) * 64 + lane], x[s], a1[ob], 0, 0, 0);
-    }
-#pragma unroll
-    for (int ob = 0; ob < 4; ++ob) {
-        a1[ob] = act4(a1[ob]);
-        a2[ob] = *reinterpret_cast<const f32x4 *>(Bp + 64 + 16 * ob + 4 * g);
-    }
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const float bq = a1[q >> 2][q & 3];
-#pragma unroll
-        for (int ob = 0; ob < 4; ++ob)
-            a2[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wp[PK_W2 + (ob * 16 + q) * 64 + lane], bq, a2[ob], 0, 0, 0);
-    }
-    f32x4 o = *reinterpret_cast<const f32x4 *>(Bp + 128 + 4 * g);
-#pragma unroll
-    for (int ob = 0; ob < 4; ++ob) a2[ob] = act4(a2[ob]);
-#pragma unroll
-    for (int q = 0; q < 16; ++q)
-        o = __builtin_amdgcn_mfma_f32_16x16x4f32(Wp[PK_W3 + q * 64 + lane], a2[q >> 2][q & 3], o, 0, 0, 0);
-    return act4(o);       // lanes with g == 0 hold (r, g, b, sigma) pre-activation-head of point j
+    for (int i = 0; i < 4; ++i) c[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    asm volatile("s_nop 1\n\t"
+                 ENARF_M32(0, 4, 8) ENARF_M32(1, 5, 8) ENARF_M32(2, 6, 8) ENARF_M32(3, 7, 8)
+                 ENARF_M32_TAIL
+                 : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3])
+                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b));
 }
 
-// ---- fp32 MLP with the activations kept, and its backward (enarf_render_bwd) ---------------------------------------
-// forward: a1, a2 = post-activation hidden layers (lane (j, g) holds units 16ob + 4g + r of point j), o = head
+// exact fp32 MLP on one 16-point tile: 112 MFMAs. KEEP: the post-activation hidden layers stay in a1 / a2 (backward).
+// lane (j, g) holds units 16ob + 4g + r of point j; o = head (lanes with g == 0 hold (r, g, b, sigma) of point j)
 __device__ __forceinline__ void mlp_tile_f32_keep(const float *__restrict__ Wp, const float *__restrict__ Bp,
                                                   const float x[8], int lane, f32x4 a1[4], f32x4 a2[4], f32x4 &o) {
     const int g = lane >> 4;
 #pragma unroll
     for (int ob = 0; ob < 4; ++ob) a1[ob] = *reinterpret_cast<const f32x4 *>(Bp + 16 * ob + 4 * g);
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
+    for (int h = 0; h < 2; ++h) {
+        float a[4][4], b[4];
 #pragma unroll
-        for (int ob = 0; ob < 4; ++ob)
-            a1[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wp[PK_W1 + (ob * 8 + s) * 64 + lane], x[s], a1[ob], 0, 0, 0);
+        for (int t = 0; t < 4; ++t) {
+            b[t] = x[4 * h + t];
+#pragma unroll
+            for (int ob = 0; ob < 4; ++ob) a[ob][t] = Wp[PK_W1 + (ob * 8 + 4 * h + t) * 64 + lane];
+        }
+        mfma32_acc4x4(a1, a, b);
     }
 #pragma unroll
     for (int ob = 0; ob < 4; ++ob) {
@@ -252,19 +284,36 @@ __device__ __forceinline__ void mlp_tile_f32_keep(const float *__restrict__ Wp, 
         a2[ob] = *reinterpret_cast<const f32x4 *>(Bp + 64 + 16 * ob + 4 * g);
     }
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const float bq = a1[q >> 2][q & 3];
+    for (int blk = 0; blk < 4; ++blk) {            // k-steps q = 4 blk + t feed hidden unit 16 blk + 4 g + t: register t of block blk
+        float a[4][4], b[4];
 #pragma unroll
-        for (int ob = 0; ob < 4; ++ob)
-            a2[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wp[PK_W2 + (ob * 16 + q) * 64 + lane], bq, a2[ob], 0, 0, 0);
+        for (int t = 0; t < 4; ++t) {
+            b[t] = a1[blk][t];
+#pragma unroll
+            for (int ob = 0; ob < 4; ++ob) a[ob][t] = Wp[PK_W2 + (ob * 16 + 4 * blk + t) * 64 + lane];
+        }
+        mfma32_acc4x4(a2, a, b);
     }
     o = *reinterpret_cast<const f32x4 *>(Bp + 128 + 4 * g);
 #pragma unroll
     for (int ob = 0; ob < 4; ++ob) a2[ob] = act4(a2[ob]);
 #pragma unroll
-    for (int q = 0; q < 16; ++q)
-        o = __builtin_amdgcn_mfma_f32_16x16x4f32(Wp[PK_W3 + q * 64 + lane], a2[q >> 2][q & 3], o, 0, 0, 0);
+    for (int h = 0; h < 2; ++h) {
+        float a[8], b[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int q = 8 * h + t;
+            a[t] = Wp[PK_W3 + q * 64 + lane];
+            b[t] = a2[q >> 2][q & 3];
+        }
+        mfma32_acc1x8(o, a, b);
+    }
     o = act4(o);
+}
+__device__ __forceinline__ f32x4 mlp_tile_f32(const float *__restrict__ Wp, const float *__restrict__ Bp, const float x[8], int lane) {
+    f32x4 a1[4], a2[4], o;
+    mlp_tile_f32_keep(Wp, Bp, x, lane, a1, a2, o);
+    return o;
 }
 // d act / d pre-activation from the post-activation value (act is monotone through 0; torch's leaky_relu uses the
 // negative slope at exactly 0)
@@ -275,19 +324,28 @@ __device__ __forceinline__ float styled_act_grad(float a) { return (a > 0.0f ? 1
 __device__ __forceinline__ void mlp_bwd_tile_f32(const float *__restrict__ Wt, const f32x4 a1[4], const f32x4 a2[4],
                                                  float dz3v, int lane, f32x4 dz2[4], f32x4 dz1[4], float dx[8]) {
     const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+    {
+        float a[4];
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob) a[ob] = Wt[PKT_W3T + ob * 64 + lane];
+        mfma32_set4x1(dz2, a, dz3v);
+    }
 #pragma unroll
     for (int ob = 0; ob < 4; ++ob) {
-        dz2[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wt[PKT_W3T + ob * 64 + lane], dz3v, zero, 0, 0, 0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) dz2[ob][r] *= styled_act_grad(a2[ob][r]);
         dz1[ob] = zero;
     }
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const float bq = dz2[q >> 2][q & 3];
+    for (int blk = 0; blk < 4; ++blk) {
+        float a[4][4], b[4];
 #pragma unroll
-        for (int ob = 0; ob < 4; ++ob)
-            dz1[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wt[PKT_W2T + (ob * 16 + q) * 64 + lane], bq, dz1[ob], 0, 0, 0);
+        for (int t = 0; t < 4; ++t) {
+            b[t] = dz2[blk][t];
+#pragma unroll
+            for (int ob = 0; ob < 4; ++ob) a[ob][t] = Wt[PKT_W2T + (ob * 16 + 4 * blk + t) * 64 + lane];
+        }
+        mfma32_acc4x4(dz1, a, b);
     }
     f32x4 d0 = zero, d1 = zero;
 #pragma unroll
@@ -295,140 +353,168 @@ __device__ __forceinline__ void mlp_bwd_tile_f32(const float *__restrict__ Wt, c
 #pragma unroll
         for (int r = 0; r < 4; ++r) dz1[ob][r] *= styled_act_grad(a1[ob][r]);
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const float bq = dz1[q >> 2][q & 3];
-        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(Wt[PKT_W1T + (0 * 16 + q) * 64 + lane], bq, d0, 0, 0, 0);
-        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(Wt[PKT_W1T + (1 * 16 + q) * 64 + lane], bq, d1, 0, 0, 0);
+    for (int h = 0; h < 2; ++h) {
+        float a[2][8], b[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int q = 8 * h + t;
+            b[t] = dz1[q >> 2][q & 3];
+            a[0][t] = Wt[PKT_W1T + (0 * 16 + q) * 64 + lane];
+            a[1][t] = Wt[PKT_W1T + (1 * 16 + q) * 64 + lane];
+        }
+        mfma32_acc2x8(d0, d1, a, b);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) { dx[r] = d0[r]; dx[4 + r] = d1[r]; }
 }
 
-// split-bf16 (NTERMS = 3: hi*hi + hi*lo + lo*hi, ~2^-16 relative) or plain bf16 (NTERMS = 1) on
-// v_mfma_f32_16x16x32_bf16: 14 (x3) MFMAs per tile
-__device__ __forceinline__ void split8(const float v[8], bf16x8 &hi, bf16x8 &lo) {
+// ---- split-precision MLP on v_mfma_f32_16x16x32_{f16,bf16} ------------------------------------------------------------
+// 3-term split (hi*hi + hi*lo + lo*hi): bf16 halves ~2^-16 relative, fp16 halves ~2^-21; 1 term = plain bf16.
+//
+// The MFMAs are issued from asm blocks that ACCUMULATE IN PLACE (vDst == SrcC, tied "+v" operands), independent chains
+// interleaved. Reason (round 2, profiles/r02_mfma_chain_hazard.md): written with the builtin, the register allocator was
+// free to give a chained MFMA a vDst different from its SrcC - `c = mfma(a, b, c)` came out as e.g.
+//     v_mfma_f32_16x16x32_f16 v[14:17], v[10:13], v[2:5], v[14:17]
+//     v_mfma_f32_16x16x32_f16 v[10:13], v[10:13], v[6:9], v[14:17]      <- SrcC = the previous vDst, vDst elsewhere
+// and the compiler put no wait state between the two (it treats "SrcC == previous vDst" as the matrix pipe's
+// back-to-back case). On gfx950 that pair does not reliably see the first result: the two split modes gave run-to-run
+// different images, pair counts and - through registers the late results landed in - samples gathered outside their
+// part's cube, while the modes whose chains happened to be allocated in place (f32, bf16) were bit-reproducible. In-place
+// chains are what every GEMM issues and need no software wait; tools/check_mfma_chains.py rejects a build whose ISA
+// contains any other chained or partially overlapping form.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split8(const float v[8], i32x4 &hi, i32x4 &lo) {          // bf16 halves, round to nearest even
+    bf16x8 h, l;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const unsigned short h = f32_to_bf16_rne(v[i]);
-        hi[i] = (short)h;
-        lo[i] = (short)f32_to_bf16_rne(v[i] - bf16_to_f32(h));
+        const unsigned short t = f32_to_bf16_rne(v[i]);
+        h[i] = (short)t;
+        l[i] = (short)f32_to_bf16_rne(v[i] - bf16_to_f32(t));
     }
+    hi = __builtin_bit_cast(i32x4, h);
+    lo = __builtin_bit_cast(i32x4, l);
 }
-template <int NTERMS>
-__device__ __forceinline__ f32x4 mma_split(const short *__restrict__ Ahl /* [hi,lo][64][8] */, const bf16x8 &bh,
-                                           const bf16x8 &bl, f32x4 c, int lane) {
-    const bf16x8 ah = *reinterpret_cast<const bf16x8 *>(Ahl + lane * 8);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
-    if (NTERMS == 3) {
-        const bf16x8 al = *reinterpret_cast<const bf16x8 *>(Ahl + 512 + lane * 8);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);
-    }
-    return c;
-}
-template <int NTERMS>
-__device__ __forceinline__ f32x4 mlp_tile_bf16(const float *__restrict__ Bp, const short *__restrict__ Hp,
-                                               const float x[8], int lane) {
-    const int g = lane >> 4;
-    f32x4 a1[4], a2[4];
-    bf16x8 bh, bl;
-    split8(x, bh, bl);
-#pragma unroll
-    for (int ob = 0; ob < 4; ++ob) {
-        a1[ob] = *reinterpret_cast<const f32x4 *>(Bp + 16 * ob + 4 * g);
-        a1[ob] = mma_split<NTERMS>(Hp + PKH_W1 + ob * 1024, bh, bl, a1[ob], lane);
-        a1[ob] = act4(a1[ob]);
-        a2[ob] = *reinterpret_cast<const f32x4 *>(Bp + 64 + 16 * ob + 4 * g);
-    }
-    f32x4 o = *reinterpret_cast<const f32x4 *>(Bp + 128 + 4 * g);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        float v[8];
-#pragma unroll
-        for (int jj = 0; jj < 8; ++jj) v[jj] = a1[2 * ks + (jj >> 2)][jj & 3];
-        split8(v, bh, bl);
-#pragma unroll
-        for (int ob = 0; ob < 4; ++ob)
-            a2[ob] = mma_split<NTERMS>(Hp + PKH_W2 + (ob * 2 + ks) * 1024, bh, bl, a2[ob], lane);
-    }
-#pragma unroll
-    for (int ob = 0; ob < 4; ++ob) a2[ob] = act4(a2[ob]);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        float v[8];
-#pragma unroll
-        for (int jj = 0; jj < 8; ++jj) v[jj] = a2[2 * ks + (jj >> 2)][jj & 3];
-        split8(v, bh, bl);
-        o = mma_split<NTERMS>(Hp + PKH_W3 + ks * 1024, bh, bl, o, lane);
-    }
-    return act4(o);
-}
-
-// split-fp16: same structure, 11-bit halves -> ~2^-21 relative
 // hi = f16 round-toward-zero (v_cvt_pkrtz_f16_f32: two values per instruction, saturates at +-65504 instead of
 // overflowing), lo = f16(x - hi): x - hi is exact in fp32 and fits 11 bits to ~2^-21 |x|
-__device__ __forceinline__ void split8h(const float v[8], f16x8 &hi, f16x8 &lo) {
+__device__ __forceinline__ void split8h(const float v[8], i32x4 &hi, i32x4 &lo) {
     typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    f16x8 h, l;
 #pragma unroll
     for (int i = 0; i < 8; i += 2) {
-        const f16x2 h = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(v[i], v[i + 1]));
-        const f16x2 l = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(v[i] - (float)h[0], v[i + 1] - (float)h[1]));
-        hi[i] = h[0]; hi[i + 1] = h[1];
-        lo[i] = l[0]; lo[i + 1] = l[1];
+        const f16x2 a = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(v[i], v[i + 1]));
+        const f16x2 r = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(v[i] - (float)a[0], v[i + 1] - (float)a[1]));
+        h[i] = a[0]; h[i + 1] = a[1];
+        l[i] = r[0]; l[i + 1] = r[1];
+    }
+    hi = __builtin_bit_cast(i32x4, h);
+    lo = __builtin_bit_cast(i32x4, l);
+}
+
+// c_i += A_i . B for four independent 16x16 output blocks (A_i: weights of block i as [hi, lo][64 lanes][8] in LDS, `stride`
+// shorts apart; B: the split activations). Term order per chain: hi*hi, hi*lo(B), lo(A)*hi. The trailing s_nop covers
+// the matrix-pipe write -> VALU read distance of the last MFMA (the compiler cannot see into the block).
+#define ENARF_MFMA4X3(OP)                                                                                                    \
+    asm volatile("s_nop 1\n\t"                                                                                              \
+                 OP " %0, %4, %12, %0\n\t" OP " %1, %5, %12, %1\n\t" OP " %2, %6, %12, %2\n\t" OP " %3, %7, %12, %3\n\t"          \
+                 OP " %0, %4, %13, %0\n\t" OP " %1, %5, %13, %1\n\t" OP " %2, %6, %13, %2\n\t" OP " %3, %7, %13, %3\n\t"          \
+                 OP " %0, %8, %12, %0\n\t" OP " %1, %9, %12, %1\n\t" OP " %2, %10, %12, %2\n\t" OP " %3, %11, %12, %3\n\t"        \
+                 "s_nop 7\n\ts_nop 1"                                                                                        \
+                 : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3])                                                            \
+                 : "v"(ah[0]), "v"(ah[1]), "v"(ah[2]), "v"(ah[3]), "v"(al[0]), "v"(al[1]), "v"(al[2]), "v"(al[3]), "v"(bh), "v"(bl))
+#define ENARF_MFMA4X1(OP)                                                                                                    \
+    asm volatile("s_nop 1\n\t"                                                                                              \
+                 OP " %0, %4, %8, %0\n\t" OP " %1, %5, %8, %1\n\t" OP " %2, %6, %8, %2\n\t" OP " %3, %7, %8, %3\n\t"              \
+                 "s_nop 7\n\ts_nop 1"                                                                                        \
+                 : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3])                                                            \
+                 : "v"(ah[0]), "v"(ah[1]), "v"(ah[2]), "v"(ah[3]), "v"(bh))
+template <bool F16, int NTERMS>
+__device__ __forceinline__ void mfma_acc4(f32x4 c[4], const short *__restrict__ A, int stride, const i32x4 &bh, const i32x4 &bl,
+                                          int lane) {
+    i32x4 ah[4], al[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        ah[i] = *reinterpret_cast<const i32x4 *>(A + i * stride + lane * 8);
+        if (NTERMS == 3) al[i] = *reinterpret_cast<const i32x4 *>(A + i * stride + 512 + lane * 8);
+    }
+    if constexpr (NTERMS == 3) {
+        if constexpr (F16) ENARF_MFMA4X3("v_mfma_f32_16x16x32_f16");
+        else ENARF_MFMA4X3("v_mfma_f32_16x16x32_bf16");
+    } else {
+        (void)bl;
+        if constexpr (F16) ENARF_MFMA4X1("v_mfma_f32_16x16x32_f16");
+        else ENARF_MFMA4X1("v_mfma_f32_16x16x32_bf16");
     }
 }
-__device__ __forceinline__ f32x4 mma_split_h(const short *__restrict__ Ahl, const f16x8 &bh, const f16x8 &bl, f32x4 c,
-                                             int lane) {
-    const f16x8 ah = *reinterpret_cast<const f16x8 *>(Ahl + lane * 8);
-    const f16x8 al = *reinterpret_cast<const f16x8 *>(Ahl + 512 + lane * 8);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, c, 0, 0, 0);
-    return c;
+// o += A0 . B0 + A1 . B1 on ONE accumulator (the last layer: two k-steps): a dependent in-place chain
+#define ENARF_MFMA1X6(OP)                                                                                                    \
+    asm volatile("s_nop 1\n\t"                                                                                              \
+                 OP " %0, %1, %5, %0\n\t" OP " %0, %1, %6, %0\n\t" OP " %0, %2, %5, %0\n\t"                                      \
+                 OP " %0, %3, %7, %0\n\t" OP " %0, %3, %8, %0\n\t" OP " %0, %4, %7, %0\n\t"                                      \
+                 "s_nop 7\n\ts_nop 1"                                                                                        \
+                 : "+v"(o)                                                                                                  \
+                 : "v"(a0h), "v"(a0l), "v"(a1h), "v"(a1l), "v"(b0h), "v"(b0l), "v"(b1h), "v"(b1l))
+#define ENARF_MFMA1X2(OP)                                                                                                    \
+    asm volatile("s_nop 1\n\t" OP " %0, %1, %3, %0\n\t" OP " %0, %2, %4, %0\n\t" "s_nop 7\n\ts_nop 1"                       \
+                 : "+v"(o) : "v"(a0h), "v"(a1h), "v"(b0h), "v"(b1h))
+template <bool F16, int NTERMS>
+__device__ __forceinline__ void mfma_acc1x2(f32x4 &o, const short *__restrict__ A, const i32x4 &b0h, const i32x4 &b0l,
+                                            const i32x4 &b1h, const i32x4 &b1l, int lane) {
+    const i32x4 a0h = *reinterpret_cast<const i32x4 *>(A + lane * 8), a1h = *reinterpret_cast<const i32x4 *>(A + 1024 + lane * 8);
+    if constexpr (NTERMS == 3) {
+        const i32x4 a0l = *reinterpret_cast<const i32x4 *>(A + 512 + lane * 8);
+        const i32x4 a1l = *reinterpret_cast<const i32x4 *>(A + 1024 + 512 + lane * 8);
+        if constexpr (F16) ENARF_MFMA1X6("v_mfma_f32_16x16x32_f16");
+        else ENARF_MFMA1X6("v_mfma_f32_16x16x32_bf16");
+    } else {
+        (void)b0l; (void)b1l;
+        if constexpr (F16) ENARF_MFMA1X2("v_mfma_f32_16x16x32_f16");
+        else ENARF_MFMA1X2("v_mfma_f32_16x16x32_bf16");
+    }
 }
-__device__ __forceinline__ f32x4 mlp_tile_f16x3(const float *__restrict__ Bp, const short *__restrict__ Hp,
-                                                const float x[8], int lane) {
+
+template <bool F16, int NTERMS>
+__device__ __forceinline__ f32x4 mlp_tile_split(const float *__restrict__ Bp, const short *__restrict__ Hp, const float x[8],
+                                                int lane) {
     const int g = lane >> 4;
     f32x4 a1[4], a2[4];
-    f16x8 bh, bl;
-    split8h(x, bh, bl);
+    i32x4 bh, bl;
+    if (F16) split8h(x, bh, bl); else split8(x, bh, bl);
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) a1[ob] = *reinterpret_cast<const f32x4 *>(Bp + 16 * ob + 4 * g);
+    mfma_acc4<F16, NTERMS>(a1, Hp + PKH_W1, 1024, bh, bl, lane);
 #pragma unroll
     for (int ob = 0; ob < 4; ++ob) {
-        a1[ob] = *reinterpret_cast<const f32x4 *>(Bp + 16 * ob + 4 * g);
-        a1[ob] = mma_split_h(Hp + PKH_W1 + ob * 1024, bh, bl, a1[ob], lane);
         a1[ob] = act4(a1[ob]);
         a2[ob] = *reinterpret_cast<const f32x4 *>(Bp + 64 + 16 * ob + 4 * g);
     }
-    f32x4 o = *reinterpret_cast<const f32x4 *>(Bp + 128 + 4 * g);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
         float v[8];
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) v[jj] = a1[2 * ks + (jj >> 2)][jj & 3];
-        split8h(v, bh, bl);
-#pragma unroll
-        for (int ob = 0; ob < 4; ++ob)
-            a2[ob] = mma_split_h(Hp + PKH_W2 + (ob * 2 + ks) * 1024, bh, bl, a2[ob], lane);
+        if (F16) split8h(v, bh, bl); else split8(v, bh, bl);
+        mfma_acc4<F16, NTERMS>(a2, Hp + PKH_W2 + ks * 1024, 2048, bh, bl, lane);
     }
-#pragma unroll
-    for (int ob = 0; ob < 4; ++ob) a2[ob] = act4(a2[ob]);
+    f32x4 o = *reinterpret_cast<const f32x4 *>(Bp + 128 + 4 * g);
+    i32x4 ch[2], cl[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
         float v[8];
 #pragma unroll
-        for (int jj = 0; jj < 8; ++jj) v[jj] = a2[2 * ks + (jj >> 2)][jj & 3];
-        split8h(v, bh, bl);
-        o = mma_split_h(Hp + PKH_W3 + ks * 1024, bh, bl, o, lane);
+        for (int jj = 0; jj < 8; ++jj) v[jj] = styled_act(a2[2 * ks + (jj >> 2)][jj & 3]);
+        if (F16) split8h(v, ch[ks], cl[ks]); else split8(v, ch[ks], cl[ks]);
     }
+    mfma_acc1x2<F16, NTERMS>(o, Hp + PKH_W3, ch[0], cl[0], ch[1], cl[1], lane);
     return act4(o);
 }
 
 template <int MODE>
 __device__ __forceinline__ f32x4 mlp_tile(const QueryCtx &S, const float x[8], int lane) {
-    if (MODE == ENARF_MLP_F16X3) return mlp_tile_f16x3(S.bias, S.mlp_h, x, lane);
+    if (MODE == ENARF_MLP_F16X3) return mlp_tile_split<true, 3>(S.bias, S.mlp_h, x, lane);
     if (MODE == ENARF_MLP_F32) return mlp_tile_f32(S.mlp, S.bias, x, lane);
-    if (MODE == ENARF_MLP_BF16X3) return mlp_tile_bf16<3>(S.bias, S.mlp_h, x, lane);
-    return mlp_tile_bf16<1>(S.bias, S.mlp_h, x, lane);
+    if (MODE == ENARF_MLP_BF16X3) return mlp_tile_split<false, 3>(S.bias, S.mlp_h, x, lane);
+    return mlp_tile_split<false, 1>(S.bias, S.mlp_h, x, lane);
 }
 
 // ---- quad (4 adjacent lanes) primitives: DPP quad_perm, no LDS -----------------------------------------------
@@ -542,7 +628,23 @@ __device__ __forceinline__ void query_tile(const QueryCtx &S, const int *cand_li
         const float qy = (g == 1) ? cz : (g == 2) ? cx : cy;
         // the pair is valid: |canonical| < 1 strictly, the precondition of make_taps_valid (lanes without a pair compute
         // garbage taps here and never use them: every load below sits behind `act`)
-#if ENARF_DIAG_GENERAL_TAPS
+#if ENARF_DIAG_TAPCHECK
+        const Taps t = make_taps(qx, qy, S.H, S.W);
+        if (act && S.diag) {
+            const Taps tv = make_taps_valid(qx, qy, S.H, S.W);
+            const int hw = S.H * S.W;
+            const bool oob = tv.o00 < 0 || tv.o00 >= hw || tv.o01 < 0 || tv.o01 >= hw || tv.o10 < 0 || tv.o10 >= hw || tv.o11 < 0 || tv.o11 >= hw;
+            const bool badk = k >= S.P;
+            const bool outside = !(fabsf(cx) < 1.0f && fabsf(cy) < 1.0f && fabsf(cz) < 1.0f);
+            if (oob || badk || outside) {
+                const unsigned long long kind = (oob ? 1ull : 0ull) | (badk ? 2ull : 0ull) | (outside ? 4ull : 0ull);
+                if (atomicAdd(&S.diag[5], 1ull) == 0ull) {
+                    S.diag[6] = (unsigned long long)S.diag_rid | ((unsigned long long)k << 32) | ((unsigned long long)lane << 40) | (kind << 48);
+                    S.diag[7] = (unsigned long long)__float_as_uint(qx) | ((unsigned long long)__float_as_uint(qy) << 32);
+                }
+            }
+        }
+#elif ENARF_DIAG_GENERAL_TAPS
         const Taps t = make_taps(qx, qy, S.H, S.W);
 #else
         const Taps t = make_taps_valid(qx, qy, S.H, S.W);

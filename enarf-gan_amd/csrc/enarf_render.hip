@@ -187,6 +187,9 @@ __global__ __launch_bounds__(256) void query_kernel(const enarf_query_args a, in
     S.feat = a.feat_cl + (size_t)b * a.feat_batch_stride;
     S.mask = a.mask_planes + (size_t)b * a.mask_batch_stride;
     S.H = a.H; S.W = a.W; S.P = a.P; S.mult_w = a.multiply_density_with_weight;
+#if ENARF_DIAG_TAPCHECK
+    S.diag = nullptr; S.diag_rid = 0;
+#endif
     int *l_cand = reinterpret_cast<int *>(scratch + 8);
     if (tid < a.P) l_cand[tid] = tid;                 // every part is a candidate for a free point cloud
     __syncthreads();
@@ -576,6 +579,9 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
         { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); if (now - ray_t0 > ray_max && n_rays) ray_max = now - ray_t0; ray_t0 = now; }
 #endif
         const uint32_t rid = (uint32_t)cur;
+#if ENARF_DIAG_TAPCHECK
+        S.diag = a.counters; S.diag_rid = rid;
+#endif
         // next entry (read after the S1 barrier): popped by the wave that has no coarse tile in this ray, when there is
         // one - the atomic's round trip then costs nothing
         const int spare_wave = (3 * SPL * 16 >= Nc) ? ((3 - (int)(rid & 3u)) & 3) : 0;

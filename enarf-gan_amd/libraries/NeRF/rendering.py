@@ -126,7 +126,7 @@ def render(model, image_coord: torch.Tensor, pose_to_camera: torch.Tensor, inv_i
     z_rend = model_input["z_rend"]
     params = model.mlp.as_dict()
     needs_grad = False
-    cl_route = bool(cfg.deformation_field) and model_input.get("tri_plane_feature") is None
+    cl_route = bool(getattr(model, "uses_warp", False)) and model_input.get("tri_plane_feature") is None
     if torch.is_grad_enabled():
         if cl_route:     # the producer emits channel-last planes: (part-probability planes NCHW, feature planes channel-last)
             tri_graph, feat_graph = model._tri_plane_pair_graph(model_input)

@@ -5,9 +5,14 @@ State-dict keys on the path: `tri_plane`, `mlp.layers.{0,1,2}.{b
 conv.modulation.weight, conv.modulation.bias, noise.weight}`, buffers `canonical_pose`,
 `canonical_bone_length`, `canonical_joints`, `canonical_parent_joints` - so reference snapshots load.
 
-Out of scope here: the StyleGAN2-ADA tri-plane generator. With `constant_triplane: False`
-the caller assigns `model.tri_plane_gen = callable(z, encoded_length, truncation_psi=...) -> (B, (32+P)*3, 256, 256)`
-or passes `model_input["tri_plane_feature"]`.
+Out of scope here: the StyleGAN2-ADA synthesis networks themselves (un-vendored in the reference).
+They plug in as callables with the reference's calling convention `net(z, encoded_length, truncation_psi=...)`, where
+`encoded_length` (B, P * 2 * num_frequency_for_other) is the bone-length positional encoding of models/narf.py:277-290:
+  * default (GAN):        `model.tri_plane_gen` -> (B, (32 + P) * 3, 256, 256)
+  * `constant_trimask`:   `model.generator`     -> (B, 96, 256, 256) feature planes; the part-probability planes are the
+                          learned constant `model.tri_plane` (1, 3P, 256, 256) x `constant_trimask_lr_mul` (narf.py:32-38)
+  * `deformation_field`:  `model.flow_generator` -> (B, 6, 256, 256) flow warping the constant feature planes (narf.py:39-58)
+or the caller passes `model_input["tri_plane_feature"]`.
 """
 import math
 from typing import Dict, List, Optional, Union
@@ -18,6 +23,7 @@ from torch import nn
 
 from .. import ops
 from ..libraries.NARF.pose_utils import transform_pose
+from ..libraries.NeRF.utils import multi_part_positional_encoding
 from ..libraries.NeRF.rendering import _parts_from_part_poses, render, render_entire_img
 
 
@@ -101,12 +107,21 @@ class TriPlaneNARF(nn.Module):
         self.temporal_state = {}
         self.buffers_tensors = {}
         self.mlp_mode = getattr(config, "mlp_mode", "f16x3") if not isinstance(config, dict) else config.get("mlp_mode", "f16x3")
-        if config.constant_triplane or config.deformation_field:
+        self.constant_trimask = bool(getattr(config, "constant_trimask", False)) and not config.constant_triplane
+        self.trimask_lr_mul = float(getattr(config, "constant_trimask_lr_mul", 1)) if self.constant_trimask else 1.0
+        if config.constant_triplane or (config.deformation_field and not self.constant_trimask):
             self.tri_plane = nn.Parameter(torch.zeros(1, 32 * 3 + self.num_bone * 3, 256, 256))
-        self.flow_generator = None         # deformation_field: assign a callable (z, *args, **kwargs) -> flow (B, 6, 256, 256)
+        elif self.constant_trimask:       # only the part-probability planes are a parameter (narf.py:34)
+            self.tri_plane = nn.Parameter(torch.zeros(1, self.num_bone * 3, 256, 256) / self.trimask_lr_mul)
+        # producer precedence as in models/narf.py:29-71: constant_triplane, constant_trimask, deformation_field, StyleGAN
+        self.uses_warp = bool(config.deformation_field) and not config.constant_triplane and not self.constant_trimask
+        self.flow_generator = None         # deformation_field: assign a callable (z, encoded_length, ...) -> flow (B, 6, 256, 256)
+        self.generator = None              # constant_trimask: assign a callable (z, encoded_length, ...) -> (B, 96, 256, 256)
         if config.constant_triplane:
             self.tri_plane_gen = lambda z, *args, **kwargs: self.tri_plane.expand(z.shape[0], -1, -1, -1)
-        elif config.deformation_field:
+        elif self.constant_trimask:
+            self.tri_plane_gen = self._trimask_tri_plane    # models/narf.py:32-38
+        elif self.uses_warp:
             self.tri_plane_gen = self._warped_tri_plane     # models/narf.py:40-58 with the HIP warp producer
         else:
             self.tri_plane_gen = None      # the StyleGAN2-ADA producer is out of scope: assign a callable
@@ -136,6 +151,11 @@ class TriPlaneNARF(nn.Module):
         return transform_pose(pose_to_camera, bone_length, self.origin_location, self.parent_id)
 
     # ---- tri-plane handling ---------------------------------------------------------------------------------------
+    def encode_bone_length(self, bone_length: torch.Tensor) -> torch.Tensor:
+        """(B, P, 1) part bone lengths -> (B, P * 2F) conditioning vector of the tri-plane producers
+        (models/narf.py:286-288: multi_part_positional_encoding(bone_length, num_frequency_for_other, num_bone)[:, :, 0])."""
+        return multi_part_positional_encoding(bone_length, self.num_frequency_for_other, num_bone=self.num_bone)[:, :, 0]
+
     def compute_tri_plane_feature(self, z, bone_length, truncation_psi=1):
         if self.tri_plane_gen is None:
             raise NotImplementedError("the StyleGAN2-ADA tri-plane generator is out of scope (SURVEY.md §2): assign "
@@ -143,7 +163,19 @@ class TriPlaneNARF(nn.Module):
         if self.config.constant_triplane:
             bs = bone_length.shape[0] if z is None else z.shape[0]
             return self.tri_plane.expand(bs, -1, -1, -1)
-        return self.tri_plane_gen(z, bone_length, truncation_psi=truncation_psi)
+        return self.tri_plane_gen(z, self.encode_bone_length(bone_length), truncation_psi=truncation_psi)
+
+    # ---- constant_trimask producer (models/narf.py:32-38) -------------------------------------------------------------
+    def _feature_planes(self, z, *args, **kwargs) -> torch.Tensor:
+        if self.generator is None:
+            raise NotImplementedError("constant_trimask: the StyleGAN2-ADA feature-plane generator is out of scope (SURVEY.md "
+                                      "§2): assign model.generator, a callable (z, encoded_length, ...) -> (B, 96, 256, 256)")
+        return self.generator(z, *args, **kwargs)
+
+    def _trimask_tri_plane(self, z, *args, **kwargs) -> torch.Tensor:
+        """cat([generator(z, ...), tri_plane.expand(B) * lr_mul], dim=1): (B, 96 + 3P, 256, 256), differentiable."""
+        feat = self._feature_planes(z, *args, **kwargs)
+        return torch.cat([feat, self.tri_plane.expand(feat.shape[0], -1, -1, -1) * self.trimask_lr_mul], dim=1)
 
     # ---- deformation-field producer (models/narf.py:40-58) ----------------------------------------------------------
     def _flow(self, z, *args, **kwargs) -> torch.Tensor:
@@ -171,7 +203,8 @@ class TriPlaneNARF(nn.Module):
     def _tri_plane_pair_graph(self, model_input: Dict):
         """Deformation field under autograd: (the tri-plane parameter - it holds the part-probability planes -, warped
         feature planes channel-last (B, 3, H, W, 32)), both differentiable; no NCHW copy of the warped planes."""
-        flow = self._flow(model_input.get("z"), model_input["bone_length"], truncation_psi=model_input.get("truncation_psi", 1))
+        flow = self._flow(model_input.get("z"), self.encode_bone_length(model_input["bone_length"]),
+                          truncation_psi=model_input.get("truncation_psi", 1))
         return self.tri_plane, _WarpCLFunction.apply(self.tri_plane, flow)
 
     def _tri_plane_pair(self, model_input: Dict):
@@ -181,8 +214,8 @@ class TriPlaneNARF(nn.Module):
         deformation field the constant planes are warped straight into the channel-last layout (one image per flow)
         and the part-probability planes stay shared."""
         tri = model_input.get("tri_plane_feature")
-        if tri is None and self.config.deformation_field:
-            flow = self._flow(model_input.get("z"), model_input["bone_length"],
+        if tri is None and self.uses_warp:
+            flow = self._flow(model_input.get("z"), self.encode_bone_length(model_input["bone_length"]),
                               truncation_psi=model_input.get("truncation_psi", 1)).detach()
             feat_cl = ops.triplane_warp_fwd(self._constant_planes_cl(), flow)
             self.buffers_tensors["tri_plane_feature"] = None      # (not materialised NCHW on this route)

@@ -454,7 +454,7 @@ def _render_args(image_coord, inv_intrinsics, parts, canonical_pose, tri_nchw, f
         a.dbg_fine_color, a.dbg_fine_valid, a.dbg_bins = _p(t["fine_color"]), _p(t["fine_valid"]), _p(t["bins"])
         o.taps = t
     if return_bins and not debug:      # the importance samples actually used (needed to replay / differentiate)
-        o.taps = {"bins": torch.empty(B, n, Nf, dtype=torch.float32, device=dev)}
+        o.taps = {"bins": torch.zeros(B, n, Nf, dtype=torch.float32, device=dev)}     # rays that are dropped keep zeros
         a.dbg_bins = _p(o.taps["bins"])
     if count:
         o.counters = torch.zeros(8, dtype=torch.int64, device=dev)

@@ -14,6 +14,48 @@ def load_golden(name):
     return dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
 
 
+def fullframe_case(name):
+    """A full-frame fixture of make_golden.run_fullframe_case -> (g, ray_validity (B, n) bool, bins (B, n, Nf) float32).
+
+    bins are rebuilt exactly as the reference formed them under the fixture's deterministic sampler: idx / Nc + 0.5 / Nc
+    in float32 (rendering.py:192-194); rays the reference dropped (B == 1, no cube hit) get 0.5 - they are never marched."""
+    g = load_golden(name)
+    B, n, Nc, Nf = int(g["batch"]), int(g["size"]) ** 2, int(g["Nc"]), int(g["Nf"])
+    rv = np.unpackbits(g["ray_validity"], axis=1)[:, :n].astype(bool)
+    idx = torch.from_numpy(g["bin_idx"].astype(np.int64))
+    rows = idx.float() / Nc + torch.full(idx.shape, 0.5) / Nc
+    if B == 1:
+        bins = torch.full((1, n, Nf), 0.5)
+        bins[0, torch.from_numpy(rv[0])] = rows
+    else:
+        bins = rows.reshape(B, n, Nf)
+    return g, rv, bins
+
+
+def u8_mismatches(ours_f32, ref_f32):
+    """Pixels whose uint8 quantisation (x * 255).astype(uint8) (ENARF_GAN_demo.py:79) differs: [(flat index, ours, ref)]."""
+    a, b = np.asarray(ours_f32, dtype=np.float32).reshape(-1), np.asarray(ref_f32, dtype=np.float32).reshape(-1)
+    qa, qb = (a * 255).astype(np.uint8), (b * 255).astype(np.uint8)
+    bad = np.nonzero(qa != qb)[0]
+    return [(int(i), float(a[i]), float(b[i])) for i in bad]
+
+
+def assert_u8_mask_matches(ours_f32, ref_f32, what, max_float_gap=1e-5, max_frac=0.02):
+    """The integer foreground mask, (mask * 255).astype(uint8) (ENARF_GAN_demo.py:79), against the reference's: equal on
+    EVERY pixel except true straddlers of a quantisation step - listed with both float values - i.e. pixels whose two
+    float masks differ by less than `max_float_gap` (10x tighter than the 1e-4 parity bound) and truncate to adjacent
+    integers. The truncating quantiser has a step at exactly 1.0, where the opaque pixels of a body sit (sum of weights =
+    1 - T_end with T_end ~ 1e-8): there a last-bit difference in the float sum flips 255 <-> 254, for the reference against
+    itself on another BLAS as much as for us. Returns the list; more than `max_frac` of the pixels is a failure."""
+    bad = u8_mismatches(ours_f32, ref_f32)
+    for i, a, b in bad:
+        assert abs(a - b) <= max_float_gap and abs(int(np.float32(a) * np.float32(255)) - int(np.float32(b) * np.float32(255))) == 1, \
+            f"{what}: pixel {i} differs in the integer mask and is not a straddler: ours {a!r} reference {b!r}"
+    n = np.asarray(ref_f32).size
+    assert len(bad) <= max_frac * n, f"{what}: {len(bad)} of {n} pixels straddle a step: {bad[:20]}"
+    return bad
+
+
 class Scene:
     """CPU-side inputs of the oracle for one synthetic scene."""
 

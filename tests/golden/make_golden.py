@@ -78,6 +78,24 @@ def install_placeholders():
 
 
 _SORT_LOG = []
+# deterministic importance sampling for the full-frame cases (run_fullframe_case): while "on", torch.multinomial returns
+# the stratified inverse-CDF bins of the weights it is given and the uniform jitter is 0.5 everywhere, so that the bins
+# the reference marches are a function of small integers that a fixture can hold for EVERY ray of a frame
+_DET = {"on": False, "idx": None}
+
+
+class _HalfJitter:
+    """stands in for torch.cuda.FloatTensor(*shape) while _DET is on: .uniform_() gives 0.5"""
+
+    def __init__(self, *shape):
+        self.shape = shape
+
+    def uniform_(self):
+        return torch.full(self.shape, 0.5)
+
+
+def _float_tensor(*shape):
+    return _HalfJitter(*shape) if _DET["on"] else torch.FloatTensor(*shape)
 
 
 def redirect_cuda_factories():
@@ -90,7 +108,19 @@ def redirect_cuda_factories():
     torch.linspace = strip(torch.linspace)
     torch.arange = strip(torch.arange)
     torch.ones = strip(torch.ones)
-    torch.cuda.FloatTensor = torch.FloatTensor
+    torch.cuda.FloatTensor = _float_tensor
+    _multinomial = torch.multinomial
+
+    def multinomial(w, num_samples, replacement=False, generator=None):
+        if not _DET["on"]:
+            return _multinomial(w, num_samples, replacement, generator=generator)
+        cdf = torch.cumsum(w.double(), dim=-1)
+        cdf = cdf / cdf[..., -1:]
+        u = ((torch.arange(num_samples, dtype=torch.float64) + 0.5) / num_samples)[None].expand(w.shape[0], -1).contiguous()
+        idx = torch.searchsorted(cdf, u, right=True).clamp(max=w.shape[-1] - 1)
+        _DET["idx"] = idx.clone()
+        return idx
+    torch.multinomial = multinomial
     _sort = torch.sort
 
     def sort(*a, **k):
@@ -221,6 +251,74 @@ def run_render_case(name, size, batch, Nc, Nf, origin_location, style_dim, n_kee
           f"mask mean {mask.mean().item():.4f} -> {os.path.getsize(path) / 1024:.0f} KiB")
 
 
+def run_fullframe_case(name, size, batch, Nc, Nf, origin_location, style_dim):
+    """EVERY ray of a frame, for bit-exact checks of the integer outputs (the uint8 foreground mask of
+    ENARF_GAN_demo.py:79, the ray-validity count): the reference renders with the deterministic sampler above and the
+    fixture keeps, per marched ray, the Nf coarse-bin indices the sampler chose (uint8), from which a test rebuilds the
+    reference's bins exactly: bins = idx / Nc + 0.5 / Nc in float32 (rendering.py:192-194)."""
+    from enarf_gan_amd import synth
+    scene = synth.make_scene(size, batch, origin_location, style_dim)
+    model = build_reference_model(scene, Nc, Nf, style_dim)
+    B, n = batch, size * size
+    _SORT_LOG.clear()
+    _DET["on"], _DET["idx"] = True, None
+    try:
+        with torch.no_grad():
+            color, mask, disp = model.forward(B, scene["image_coord"], scene["pose_to_camera"], scene["inv_intrinsics"], None,
+                                              scene["z_rend"], scene["bone_length"], Nc=Nc, Nf=Nf, return_disparity=True)
+    finally:
+        _DET["on"] = False
+    from libraries.NeRF.rendering import decide_frustrum_range
+    from libraries.NARF.pose_utils import transform_pose
+    pose_p, _ = transform_pose(scene["pose_to_camera"], scene["bone_length"], origin_location, scene["parents"])
+    pose_s = pose_p.clone()
+    pose_s[:, :, :3, 3] *= 3
+    _, _, _, rval = decide_frustrum_range(scene["image_coord"], pose_s, scene["inv_intrinsics"], 0.3, 5,
+                                          return_camera_coord=True)
+    rval = rval.reshape(B, n)
+    idx = _DET["idx"]                                  # (rows, Nf): rows = marched rays (valid ones when B == 1)
+    rows = int(rval.sum()) if B == 1 else B * n
+    assert idx.shape == (rows, Nf) and int(idx.max()) < Nc <= 255
+    bins_ref = _SORT_LOG[-1].reshape(rows, Nf)
+    rebuilt = idx.float() / Nc + torch.full((rows, Nf), 0.5) / Nc
+    assert torch.equal(bins_ref, rebuilt), "the fixture's bin indices must reproduce the reference's bins exactly"
+    out = dict(size=size, batch=batch, Nc=Nc, Nf=Nf, style_dim=style_dim, origin_location=origin_location,
+               ray_validity=np.packbits(rval.numpy(), axis=1), n_valid_rays=rval.sum(dim=1).numpy(),
+               bin_idx=idx.numpy().astype(np.uint8),
+               mask=mask.numpy(), mask_u8=(mask.numpy() * 255).astype(np.uint8),
+               color_u8=np.clip(color.numpy() * 127.5 + 127.5, 0, 255).astype(np.uint8),
+               disparity_sum=float(disp.double().sum()), color_abs_sum=float(color.double().abs().sum()))
+    path = os.path.join(HERE, f"{name}.npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: valid rays {rval.sum().item()}/{B * n}, mask_u8 sum {int(out['mask_u8'].astype(np.int64).sum())} "
+          f"-> {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def run_encoding_case(name, seed):
+    """The host-side encodings of libraries/NeRF/utils.py:46-88 (the bone-length conditioning of the tri-plane producers,
+    models/narf.py:286-288) and to_local / in_cube (:13-43) on small random inputs."""
+    from libraries.NeRF.utils import in_cube, multi_part_positional_encoding, positional_encoding, to_local
+    from enarf_gan_amd import synth
+    g = torch.Generator().manual_seed(seed)
+    scene = synth.make_scene(32, 3, "center+head", 20)
+    from libraries.NARF.pose_utils import transform_pose
+    pose_p, bl_p = transform_pose(scene["pose_to_camera"], scene["bone_length"], "center+head", scene["parents"])
+    bl = bl_p.clone()
+    bl[0, 3, 0] = 1.25                                          # a bone longer than 1: its channels are masked to zero
+    x = torch.randn(2, 5, 7, generator=g)
+    val = torch.rand(2, 24 * 3, 11, generator=g) * 2.4 - 1.2     # some parts leave [-1, 1]
+    pts = torch.randn(3, 3, 50, generator=g) * 2 + torch.tensor([0.0, 0.0, 3.0])[None, :, None]
+    out = dict(bone_length=bl.numpy(), enc_length=multi_part_positional_encoding(bl, 4, 24)[:, :, 0].numpy(),
+               x=x.numpy(), pe_cos_first=positional_encoding(x, 6).numpy(),
+               pe_sin_first_cat1=positional_encoding(x, 3, cos_first=False, cat_dim=1).numpy(),
+               val=val.numpy(), mpe=multi_part_positional_encoding(val, 2, 24).numpy(),
+               pts=pts.numpy(), local=to_local(pts, pose_p).numpy(), inside=in_cube(to_local(pts, pose_p)).numpy(),
+               inside3=in_cube(pts[:, :, :] / 4).numpy())
+    path = os.path.join(HERE, f"{name}.npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: masked channels {int((out['enc_length'] == 0).sum())} -> {os.path.getsize(path) / 1024:.0f} KiB")
+
+
 def run_query_case(name, batch, n_points, origin_location, style_dim, seed):
     """calc_density_and_color_from_camera_coord_v2 (models/narf.py:176) on a point cloud."""
     from enarf_gan_amd import synth
@@ -331,6 +429,13 @@ def main():
         run_render_case("render_c4s_32_b2", size=32, batch=2, Nc=72, Nf=96, origin_location="center_fixed",
                         style_dim=256, n_keep=96, seed=25)
         return
+    if "--only-encoding" in sys.argv:
+        run_encoding_case("encoding", seed=41)
+        return
+    if "--only-full" in sys.argv:   # every ray of a frame, deterministic sampler: bit-exact integer outputs
+        run_fullframe_case("full_c1_128_b1_p23", size=128, batch=1, Nc=48, Nf=64, origin_location="center_fixed", style_dim=20)
+        run_fullframe_case("full_gan_32_b2", size=32, batch=2, Nc=48, Nf=64, origin_location="center_fixed", style_dim=256)
+        return
     if "--only-grad" in sys.argv:
         run_grad_case("grad_32_b1", size=32, batch=1, Nc=48, Nf=32, origin_location="center_fixed", style_dim=20,
                       n_rays=72, seed=31)
@@ -354,6 +459,9 @@ def main():
                   n_rays=48, seed=32)
     run_render_case("render_c4s_32_b2", size=32, batch=2, Nc=72, Nf=96, origin_location="center_fixed",
                     style_dim=256, n_keep=96, seed=25)
+    run_fullframe_case("full_c1_128_b1_p23", size=128, batch=1, Nc=48, Nf=64, origin_location="center_fixed", style_dim=20)
+    run_fullframe_case("full_gan_32_b2", size=32, batch=2, Nc=48, Nf=64, origin_location="center_fixed", style_dim=256)
+    run_encoding_case("encoding", seed=41)
 
 
 if __name__ == "__main__":

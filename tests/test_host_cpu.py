@@ -91,6 +91,20 @@ def test_tap_offsets_stay_inside_the_plane(tmp_path):
     assert int(r.stdout.split()[1]) > 100000
 
 
+def test_built_library_has_only_in_place_mfma_chains():
+    """ISA lint of the built library (tools/check_mfma_chains.py): a chained MFMA whose vDst differs from its SrcC, or
+    partially overlaps it, is issued by the compiler without a wait state and does not reliably see its predecessor's
+    result on gfx950 - the cause of the round-1 renderer's run-to-run differences in the split-precision MLP modes."""
+    import importlib.util
+    from enarf_gan_amd import build
+    spec = importlib.util.spec_from_file_location("check_mfma_chains", os.path.join(ROOT, "tools", "check_mfma_chains.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    kernels, n_mfma, problems = mod.check(build.LIB)
+    assert n_mfma > 1000 and kernels > 20
+    assert not problems, problems[:5]
+
+
 def test_product_reads_no_environment_switches():
     """A renderer whose output changes with an environment variable is a defect: the product sources
     read none, and the library path can only be changed by an explicit use_variant() call from a measurement tool."""
@@ -169,11 +183,72 @@ def test_ray_samplers_match_reference_formulas():
     grid, homo = whole_image_grid_ray_sampler(16, 16, 2, device="cpu")
     assert torch.equal(homo, synth.pixel_centres(16, 2))
     assert grid.shape == (2, 16, 16, 2) and float(grid.min()) == -1 + 1 / 16
+    # a patch coarser than the frame: centres scale with render_size / patch_size (ray_sampler.py:58)
+    grid2, homo2 = whole_image_grid_ray_sampler(128, 32, 1, device="cpu")
+    assert float(homo2[0, 0, 0, 0]) == 2.0 and float(homo2[0, 0, 1, 33]) == 6.0 and float(grid2[0, 1, 0, 1]) == 6.0 / 64 - 1
     mask = torch.zeros(1, 32, 32)
-    mask[0, 10:20, 12:18] = 1
-    idx, homo = mask_based_sampler(mask, 64)
-    assert idx.shape == (1, 64) and homo.shape == (1, 1, 3, 64)
-    assert torch.equal(homo[0, 0, 0], (idx[0] % 32).float() + 0.5)
+    with pytest.raises(Exception):          # device op: no CPU path
+        mask_based_sampler(mask, 64)
+
+
+def test_host_encodings_match_reference_golden(golden_dir):
+    """libraries/NeRF/utils.py mirror (positional encodings, to_local, in_cube) against values recorded from the reference
+    (tests/golden/encoding.npz) - bit-exact: the mirror rounds in the same order ((x 2^f) pi)."""
+    from enarf_gan_amd import synth
+    from enarf_gan_amd.libraries.NARF.pose_utils import transform_pose
+    from enarf_gan_amd.libraries.NeRF.utils import in_cube, multi_part_positional_encoding, positional_encoding, to_local
+    g = dict(np.load(os.path.join(golden_dir, "encoding.npz"), allow_pickle=False))
+    t = lambda k: torch.from_numpy(g[k])
+    assert torch.equal(multi_part_positional_encoding(t("bone_length"), 4, 24)[:, :, 0], t("enc_length"))
+    assert torch.equal(positional_encoding(t("x"), 6), t("pe_cos_first"))
+    assert torch.equal(positional_encoding(t("x"), 3, cos_first=False, cat_dim=1), t("pe_sin_first_cat1"))
+    assert torch.equal(multi_part_positional_encoding(t("val"), 2, 24), t("mpe"))
+    scene = synth.make_scene(32, 3, "center+head", 20)
+    pose_p, _ = transform_pose(scene["pose_to_camera"], scene["bone_length"], "center+head", scene["parents"])
+    loc = to_local(t("pts"), pose_p)
+    assert loc.shape == t("local").shape and torch.allclose(loc, t("local"), rtol=0, atol=2e-6)   # torch.matmul order
+    assert torch.equal(in_cube(t("local")), t("inside")) and torch.equal(in_cube(t("pts") / 4), t("inside3"))
+
+
+def test_tri_plane_producers_get_the_encoded_bone_length():
+    """models/narf.py:277-290: producers are conditioned on the bone-length positional encoding, not on the raw lengths;
+    constant_trimask (narf.py:32-38) = generator feature planes + the learned part-probability planes x lr_mul."""
+    from enarf_gan_amd import synth
+    from enarf_gan_amd.libraries.NeRF.utils import multi_part_positional_encoding
+    from enarf_gan_amd.models.narf import TriPlaneNARF
+    bl = torch.rand(2, 23, 1) * 0.5 + 0.1
+    seen = {}
+
+    def producer(z, enc, truncation_psi=1):
+        seen["enc"], seen["psi"] = enc, truncation_psi
+        return torch.zeros(z.shape[0], 165, 4, 4)
+    m = TriPlaneNARF(_nerf_cfg(constant_triplane=False), 20, 24, parent=synth.SMPL_PARENTS)
+    m.tri_plane_gen = producer
+    m.compute_tri_plane_feature(torch.zeros(2, 20), bl, truncation_psi=0.4)
+    assert seen["enc"].shape == (2, 23 * 2 * 4) and seen["psi"] == 0.4
+    assert torch.equal(seen["enc"], multi_part_positional_encoding(bl, 4, 23)[:, :, 0])
+    # constant_trimask
+    m = TriPlaneNARF(_nerf_cfg(constant_triplane=False, constant_trimask=True, constant_trimask_lr_mul=10), 20, 24,
+                     parent=synth.SMPL_PARENTS)
+    assert m.tri_plane.shape == (1, 69, 256, 256)
+    with pytest.raises(NotImplementedError, match="constant_trimask"):
+        m.compute_tri_plane_feature(torch.zeros(2, 20), bl)
+    m.generator = lambda z, enc, truncation_psi=1: torch.ones(z.shape[0], 96, 256, 256) * enc[:, :1, None, None]
+    with torch.no_grad():
+        m.tri_plane.fill_(0.25)
+    tri = m.compute_tri_plane_feature(torch.zeros(2, 20), bl)
+    assert tri.shape == (2, 165, 256, 256) and float(tri[0, 96, 0, 0]) == 2.5 and tri.requires_grad
+    assert torch.equal(tri[:, 0, 0, 0], multi_part_positional_encoding(bl, 4, 23)[:, 0, 0])
+    # deformation field: the flow generator gets the encoding as well (checked on the CPU up to the HIP call)
+    m = TriPlaneNARF(_nerf_cfg(constant_triplane=False, deformation_field=True), 20, 24, parent=synth.SMPL_PARENTS)
+
+    def flow(z, enc, truncation_psi=1):
+        seen["flow_enc"] = enc
+        raise RuntimeError("stop before the device call")
+    m.flow_generator = flow
+    with pytest.raises(RuntimeError, match="stop before"):
+        m.compute_tri_plane_feature(torch.zeros(2, 20), bl)
+    assert seen["flow_enc"].shape == (2, 184)
 
 
 def test_unsupported_configs_raise():
