@@ -158,6 +158,9 @@ SIGNATURES = {
     "enarf_render_bwd": (C.c_int, [C.POINTER(RenderBwdArgs), C.c_void_p]),
     "enarf_prepare_bwd": (C.c_int, [C.POINTER(PrepareBwdArgs), C.c_void_p]),
     "enarf_triplane_unpack_add": (C.c_int, [_f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "enarf_mask_topk_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "enarf_mask_dilate_topk": (C.c_int, [_f32p, _f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                         C.c_void_p]),
 }
 
 _lib: Optional[C.CDLL] = None

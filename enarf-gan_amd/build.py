@@ -14,7 +14,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(CSRC, "libenarf_hip.so")
-SOURCES = ["enarf_render.hip", "enarf_render_bwd.hip", "enarf_sampler.hip"]
+SOURCES = ["enarf_render.hip", "enarf_render_bwd.hip", "enarf_sampler.hip", "enarf_raysample.hip"]
 HEADERS = ["enarf_device.h", "enarf_query.h", "enarf_march.h", "enarf_host.h", os.path.join(ROOT, "include", "enarf_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
          "-I", os.path.join(ROOT, "include"), "-I", CSRC]

@@ -116,6 +116,24 @@ def triplane_sample_bwd(grad_out: torch.Tensor, inp: torch.Tensor, grid: torch.T
     return gi, gg
 
 
+# ---------------------------------------------------------------------------------------- a16 ray sampler
+@_on_tensor_device
+def mask_dilate_topk(mask: torch.Tensor, noise: torch.Tensor, k: int, radius: int = 64) -> torch.Tensor:
+    """mask (B, h, w), noise (B, h*w) -> (B, k) int64 flat pixel ids of the k largest dilate(mask) + noise per image
+    (libraries/NeRF/ray_sampler.py:23-30), unordered."""
+    lib = _lib.load()
+    m = _dev_f32(mask, "mask")
+    nz = _dev_f32(noise, "noise")
+    B, h, w = m.shape
+    if nz.shape != (B, h * w):
+        raise ValueError(f"noise {tuple(nz.shape)} must be (B, h*w) = {(B, h * w)}")
+    out = torch.empty(B, k, dtype=torch.int64, device=m.device)
+    ws = torch.empty(int(lib.enarf_mask_topk_workspace_bytes(B, h, w)) // 4, dtype=torch.float32, device=m.device)
+    _lib.check(lib.enarf_mask_dilate_topk(_p(m), _p(nz), _p(out), B, h, w, int(k), int(radius), _p(ws), _stream(m.device)),
+               "enarf_mask_dilate_topk")
+    return out
+
+
 # ---------------------------------------------------------------------------------------- re-layout
 @_on_tensor_device
 def triplane_pack(tri_nchw: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -337,6 +337,17 @@ int enarf_triplane_warp_fwd(const float *src_cl, const float *flow, float *out_c
 int enarf_triplane_warp_bwd(const float *g_out_cl, const float *src_cl, const float *flow, float *g_src_cl,
                             float *g_flow, int B, int H, int W, enarf_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * a16. mask_based_sampler on the device (libraries/NeRF/ray_sampler.py:7-39): per image the k largest values of
+ *   max_pool2d(mask, 2 radius + 1, stride 1, padding radius) + noise   (the reference: radius 64, noise ~ U[0, 1))
+ * as flat pixel ids y * w + x, unordered (torch.topk(sorted=False)); scores equal to the k-th largest are taken in
+ * ascending pixel order. mask (B, h, w) fp32, noise (B, h * w) fp32, out_idx (B, k) int64; workspace:
+ * enarf_mask_topk_workspace_bytes(B, h, w) bytes of device memory. Separable window maximum + one radix select per image.
+ * --------------------------------------------------------------------------------------------- */
+size_t enarf_mask_topk_workspace_bytes(int B, int h, int w);
+int enarf_mask_dilate_topk(const float *mask, const float *noise, long long *out_idx, int B, int h, int w, int k, int radius,
+                           void *workspace, enarf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
