@@ -1,15 +1,19 @@
 #!/usr/bin/env python3
 """bench.py - rendered rays/s of the fused HIP ray march on synthetic 128x128 frames.
 
-Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched with
-torch.distributed.run, one rank per GPU. One step = one pass of the hot path over one batch of rays that
-is already resident in HBM: enarf_render_step_fwd = one pre-march launch (part frames + modulated MLP weights,
-NCHW -> channel-last feature planes, ray set-up) + the fused ray march (in-kernel importance sampling); with
---unfused the same work as enarf_prepare -> enarf_triplane_pack -> enarf_render_fwd. Rank 0 prints ONE JSON line. Weak scaling: every rank renders its own frame(s); the path
-has no exchange step, so there is no data-path collective.
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched with torch.distributed.run, one
+rank per GPU. One step = one pass of the hot path over one batch of rays that is already resident in HBM:
+enarf_render_step_fwd = one pre-march launch (part frames + modulated MLP weights, NCHW -> channel-last feature planes, ray
+set-up) + the fused ray march (in-kernel importance sampling). Rank 0 prints ONE JSON line.
 
-Workload = BASELINE.json configs[1]: 128x128 rays, Nc 48 + Nf 64 samples/ray, 24 SMPL joints (P = 23
-parts, `center_fixed`), one frame per GPU per step, fp32 tri-plane, constant (DSO-style) tri-plane.
+Workloads (BASELINE.json `configs`):
+  N = 1   configs[1] "C1": one DSO-style 128x128 frame, Nc 48 + Nf 64 samples/ray, 24 SMPL joints (P = 23 parts), constant
+          fp32 tri-plane - the configuration the headline metric is quoted on.
+  N > 1   configs[3] "C3" shape: a FIXED batch of 64 GAN-style frames (one tri-plane per frame) of 128x128 rays, dealt
+          64 / N per rank (`scaling: strong`, per-GPU work shrinks with N). The forward path has no exchange step (SURVEY.md
+          8e): the only collectives are the barrier and the MAX-reduce of wall time - unless `--train-step` is given, which
+          times forward + backward + the RCCL gradient all-reduce of the renderer's parameters (constant tri-plane 43 MB +
+          StyledMLP), the collective a data-parallel training step has (train_ENARF_GAN.py:203-206).
 """
 from __future__ import annotations
 
@@ -25,8 +29,13 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+# MI355X_MICROARCH.md: HBM3E 8 TB/s spec; L2 ~34.5 TB/s aggregate; vector L1 / texture path 64 B/clk/CU; 256 CUs
+HBM_PEAK_GBS = 8000.0
+L2_PEAK_GBS = 34500.0
+NUM_CUS = 256
+L1_BYTES_PER_CLK_PER_CU = 64.0
 BF16_DENSE_TFLOPS = 2500.0
+C3_GLOBAL_FRAMES = 64
 
 
 def parse():
@@ -35,38 +44,32 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--size", type=int, default=128)
-    ap.add_argument("--batch", type=int, default=1, help="frames per GPU per step")
+    ap.add_argument("--batch", type=int, default=None, help="frames per GPU per step (default: 1 at N = 1, 64 / N at N > 1)")
     ap.add_argument("--nc", type=int, default=48)
     ap.add_argument("--nf", type=int, default=64)
     ap.add_argument("--origin", default="center_fixed", choices=["center", "center_fixed", "center+head"])
     ap.add_argument("--mlp-mode", default="f16x3", choices=["f32", "f16x3", "bf16x3", "bf16"])
     ap.add_argument("--style-dim", type=int, default=20)
     ap.add_argument("--early-stop-eps", type=float, default=0.0, help="opt-in early ray termination (0 = exact)")
-    ap.add_argument("--cache-triplane", action="store_true",
-                    help="re-lay the (constant) tri-plane once instead of every step")
+    ap.add_argument("--cache-triplane", action="store_true", help="re-lay the (constant) tri-plane once instead of every step")
     ap.add_argument("--distinct-triplanes", action="store_true",
-                    help="GAN style: one tri-plane per frame (generated on the device) instead of one shared constant tri-plane")
+                    help="GAN style: one tri-plane per frame instead of one shared constant tri-plane (default at N > 1)")
     ap.add_argument("--streams", type=int, default=1,
-                    help="HIP streams the steps alternate over, each with its own intermediates (part frames, MLP packs, "
-                         "channel-last planes, workspace). With 2, the pre-march launch of step i+1 fills the CUs that the "
-                         "persistent march of step i frees in its tail (+4 %% rays/s), but event-bracketed kernel times then "
-                         "include the overlap, so the default - and the roofline figure - is strictly serial steps")
+                    help="HIP streams the steps alternate over, each with its own intermediates; with 2 the pre-march launch of "
+                         "step i+1 fills the CUs the persistent march of step i frees in its tail, but event-bracketed kernel "
+                         "times then include the overlap, so the default - and the roofline figure - is strictly serial steps")
     ap.add_argument("--shard-frame", action="store_true",
-                    help="N > 1: strong scaling of ONE frame batch - every rank marches its contiguous share of the rays "
-                         "(sharding.rays_for_rank) and the 5 floats per ray are all-gathered on every rank each step "
-                         "(SURVEY.md 8e, single DSO frame); default is weak scaling, one frame batch per rank")
-    ap.add_argument("--unfused", action="store_true",
-                    help="issue prepare / re-layout / render as the three separate C-ABI calls (4 launches) "
-                         "instead of enarf_render_step_fwd (2 launches)")
+                    help="N > 1: cut ONE frame batch by rays (sharding.rays_for_rank) and all-gather the 5 floats per ray")
+    ap.add_argument("--train-step", action="store_true",
+                    help="time forward + backward (enarf_render_bwd + weight gradients) + the gradient all-reduce "
+                         "(sharding.all_reduce_gradients: constant tri-plane + StyledMLP parameters) instead of the forward alone")
+    ap.add_argument("--unfused", action="store_true", help="issue prepare / re-layout / render as the three separate C-ABI calls")
     ap.add_argument("--spinup-ms", type=float, default=40.0,
-                    help="device spin-up during set-up, before the W warm-up steps: the step is repeated until this much "
-                         "wall time has passed, so that short runs (small K and W) are not timed at idle clocks")
-    ap.add_argument("--no-p24", action="store_true",
-                    help="skip the extra timed pass with origin_location center+head (P = 24), which SURVEY.md 8 asks to "
-                         "report beside the shipping P = 23 configuration")
+                    help="device spin-up during set-up, before the W warm-up steps (not part of W or K)")
+    ap.add_argument("--no-p24", action="store_true", help="skip the extra timed pass with origin_location center+head (P = 24)")
+    ap.add_argument("--no-f32", action="store_true", help="skip the extra timed pass with the exact fp32 MLP arithmetic")
     ap.add_argument("--allow-variant", action="store_true", help="measurement only: permit --variant")
-    ap.add_argument("--variant", default=None, help="path of another build of the same ABI (tools/build_variant.sh); "
-                                                     "refused without --allow-variant")
+    ap.add_argument("--variant", default=None, help="another build of the same ABI (tools/build_variant.sh); needs --allow-variant")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=4096, help="rays of the same frame per CPU pass (middle band)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="repeat CPU passes until this much time is spent")
@@ -82,21 +85,36 @@ def cpu_baseline(scene_cpu, Nc, Nf, n_rays, budget_s):
     pose_p, bl_p = O.transform_pose(s["pose_to_camera"], s["bone_length"], s["origin_location"], s["parents"])
     cpose, cbl = O.register_canonical_pose(s["canonical_pose"], s["parents"], s["origin_location"])
     n = s["image_coord"].shape[-1]
-    # a horizontal band through the middle of the frame (hits and misses mixed, like the full frame)
-    start = (n // 2) - n_rays // 2
-    coord = s["image_coord"][..., start:start + n_rays].contiguous()
+    start = (n // 2) - n_rays // 2            # a horizontal band through the middle of the frame (hits and misses mixed)
+    coord = s["image_coord"][:1, ..., start:start + n_rays].contiguous()
     g = torch.Generator().manual_seed(0)
     passes, t0 = 0, time.perf_counter()
     while True:
-        O.render(coord, pose_p, bl_p, s["inv_intrinsics"], cpose, cbl, s["tri_plane"], s["mlp"], s["z_rend"],
+        O.render(coord, pose_p[:1], bl_p[:1], s["inv_intrinsics"][:1], cpose, cbl, s["tri_plane"][:1], s["mlp"], s["z_rend"][:1],
                  s["coordinate_scale"], Nc, Nf, generator=g, use_grid_sample=True)
         passes += 1
         dt = time.perf_counter() - t0
         if dt >= budget_s or passes >= 64:
             break
     return {"value": passes * n_rays / dt, "unit": "rays/s", "cores": cores, "kind": "port",
-            "sample": f"{n_rays} consecutive rays of the same frame (middle band: hits and misses mixed), {passes} passes, "
+            "sample": f"{n_rays} consecutive rays of one frame (middle band: hits and misses mixed), {passes} passes, "
                       f"{dt:.1f} s; oracle/enarf_oracle.py render() with F.grid_sample"}
+
+
+def counter_fractions(workload_key, kernel_ms):
+    """Counter-backed utilisation of the march from the committed rocprofv3 summary (profiles/r02_roofline.json, written
+    by tools/pmc_summary.py from separate --pmc passes of this very command). Attached only when the profiled workload is
+    the one being run; every entry names its counters and its source file."""
+    path = os.path.join(ROOT, "profiles", "r02_roofline.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        prof = json.load(open(path))
+    except Exception:
+        return None
+    if prof.get("workload_key") != workload_key:
+        return None
+    return prof
 
 
 def main():
@@ -129,26 +147,38 @@ def main():
         if not args.allow_variant:
             raise SystemExit("--variant needs --allow-variant (the default bench measures the in-tree library only)")
         _lib.use_variant(args.variant)
-    from enarf_gan_amd import ops, synth
-    from oracle import enarf_oracle as O   # only for the canonical-pose buffers of the synthetic scene and the cpu_baseline leg
+    from enarf_gan_amd import ops, sharding, synth
+    from enarf_gan_amd.models.narf import TriPlaneNARF
 
-    S, B, Nc, Nf = args.size, args.batch, args.nc, args.nf
+    S, Nc, Nf = args.size, args.nc, args.nf
     shard = args.shard_frame and world > 1
-    sc = synth.make_scene(S, B, args.origin, args.style_dim, pose_seed=1234 + (0 if shard else 100 * rank), shared_triplane=True)
+    multi = world > 1 and not shard
+    if args.batch is not None:
+        B = args.batch
+    elif multi:
+        B = sharding.batch_share(C3_GLOBAL_FRAMES, rank, world)[1]
+    else:
+        B = 1
+    distinct = (args.distinct_triplanes or (multi and not args.train_step)) and B > 1
+    # frames: rank r of the C3 batch renders frames [r B, (r + 1) B) of one global batch (pose seeds are per frame)
+    first_frame = sharding.batch_share(world * B, rank, world)[0] if multi else 0
+    sc = synth.make_scene(S, B, args.origin, args.style_dim, pose_seed=1234 + first_frame, shared_triplane=True)
     n_frame = S * S
     n = n_frame
     P = sc["num_parts"]
-    cpose, cbl = O.register_canonical_pose(sc["canonical_pose"], sc["parents"], args.origin)
+    # canonical buffers from the product's own register_canonical_pose (models/narf.py:84-120)
+    cfg = synth.nerf_config(origin_location=args.origin, Nc=Nc, Nf=Nf)
+    model = TriPlaneNARF(cfg, args.style_dim, 24, parent=sc["parents"], num_bone_param=23)
+    model.register_canonical_pose(sc["canonical_pose"])
+    cpose_d, cbl_d = model.canonical_pose.to(dev), model.canonical_bone_length.to(dev)
     d = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in sc.items()}
     tri = sc["tri_plane"][:1].contiguous().to(dev)          # one constant tri-plane shared by the batch (DSO style)
-    if args.distinct_triplanes and B > 1:                   # per-frame tri-planes: jittered copies, made on the device
-        g = torch.Generator(device=dev).manual_seed(5)
+    if distinct:                                            # per-frame tri-planes: jittered copies, made on the device
+        g = torch.Generator(device=dev).manual_seed(5 + first_frame)
         tri = (tri + 0.05 * torch.randn(B, *tri.shape[1:], device=dev, generator=g)).contiguous()
     mlp = {k: v.to(dev) for k, v in sc["mlp"].items()}
-    cpose_d, cbl_d = cpose.to(dev), cbl.to(dev)
     coord = d["image_coord"].reshape(B, 3, n).contiguous()
     if shard:                                   # this rank's contiguous range of every frame's rays
-        from enarf_gan_amd import sharding
         coord = coord[..., sharding.rays_for_rank(n_frame, rank, world)].contiguous()
         n = coord.shape[-1]
 
@@ -159,7 +189,7 @@ def main():
             return sharding.all_gather_rays(local, n_frame)
         return sharding.all_gather_rays(local.cpu(), n_frame)        # rehearsal backends move host tensors
 
-    n_streams = 1 if args.unfused else max(1, args.streams)
+    n_streams = 1 if (args.unfused or args.train_step) else max(1, args.streams)
     streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(n_streams - 1)]
     sets = []                                      # per-stream intermediates: steps on different streams share only inputs
     for _ in range(n_streams):
@@ -169,14 +199,43 @@ def main():
     feat_cl, parts, pack = sets[0]
     torch.cuda.synchronize()
 
-    def bound_step(seed, count=False, k=0):
+    def bound_step(seed, count=False, k=0, mode=None, return_bins=False):
         f, pa, pk = sets[k]
         return ops.RenderStep(d["pose_to_camera"], d["bone_length"], cbl_d, d["z_rend"], mlp, sc["parents"], args.origin,
                               3.0, coord, d["inv_intrinsics"], cpose_d, tri, f, Nc, Nf, parts_out=pa,
-                              pack_out=pk, relayout=not args.cache_triplane, seed=seed, mlp_mode=args.mlp_mode,
-                              want_fine=True, count=count, early_stop_eps=args.early_stop_eps)
+                              pack_out=pk, relayout=not args.cache_triplane, seed=seed, mlp_mode=mode or args.mlp_mode,
+                              want_fine=True, count=count, early_stop_eps=args.early_stop_eps, return_bins=return_bins)
+
+    # ---- the training step (opt-in): forward + backward + gradient all-reduce of the renderer's parameters
+    train_params = None
+    if args.train_step:
+        if Nf > 64:
+            raise SystemExit("--train-step: the backward handles Nf <= 64")
+        tri_param = torch.nn.Parameter(tri.clone())
+        mlp_params = {k: torch.nn.Parameter(v.clone()) for k, v in mlp.items() if "noise" not in k}
+        train_params = [tri_param] + [mlp_params[k] for k in sorted(mlp_params)]
+        g_color = torch.randn(B, 3, n, device=dev)
+        g_mask = torch.randn(B, n, device=dev)
+
+    def train_step(i):
+        st = bound_step(99 + i, return_bins=True)
+        o = st.run()
+        grad_tri, dW, db = ops.render_bwd(coord, d["inv_intrinsics"], st.parts, cpose_d, tri, st.feat_cl, st.pack, Nf,
+                                          o.taps["bins"], g_color, g_mask)
+        pg, dz = ops.prepare_bwd(d["z_rend"], mlp, dW)
+        train_params[0].grad = grad_tri
+        for kname in sorted(mlp_params):
+            leaf = kname.split(".", 2)[2]
+            layer = int(kname.split(".")[1])
+            mlp_params[kname].grad = (db[layer].reshape(mlp_params[kname].shape) if leaf == "bias"
+                                      else pg[kname].reshape(mlp_params[kname].shape))
+        if dist is not None:
+            sharding.all_reduce_gradients(train_params, world)
+        return o
 
     def step(i, count=False):
+        if args.train_step:
+            return train_step(i)
         if not args.unfused:
             o = bound_step(99 + i, count).run()
             if shard:
@@ -191,20 +250,22 @@ def main():
                               early_stop_eps=args.early_stop_eps)
 
     # algorithmic work of one step, counted by the kernel itself in an untimed pass (same inputs, same seed)
-    cnt = step(0, count=True).counters
+    cnt = bound_step(99, count=True).run().counters
     torch.cuda.synchronize()
     V, tiles, rays_marched, rounds = [int(x) for x in cnt[:4].tolist()]
+    if int(cnt[7]) != 0:
+        raise SystemExit("the march's scheduler watchdog fired (counters[7] != 0): results are incomplete")
 
     # set-up: bring the device out of its idle clocks (reported in config.spinup_ms; not part of W or K)
     t_spin = time.perf_counter()
     while (time.perf_counter() - t_spin) * 1e3 < args.spinup_ms:
         for _ in range(8):
-            step(0)
+            bound_step(99).run()
         torch.cuda.synchronize()
 
     for i in range(args.warmup):
         with torch.cuda.stream(streams[i % n_streams]):
-            if args.unfused:
+            if args.unfused or args.train_step:
                 step(i)
             else:
                 o = bound_step(99 + i, k=i % n_streams).run()
@@ -217,6 +278,11 @@ def main():
         dist.barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
+        if args.train_step:
+            ev0[i].record()
+            train_step(i)
+            ev1[i].record()
+            continue
         if not args.unfused:      # same two launches as enarf_render_step_fwd(ENARF_STEP_ALL), with the march bracketed
             k = i % n_streams
             with torch.cuda.stream(streams[k]):
@@ -246,72 +312,105 @@ def main():
         elapsed = float(t.item())
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
 
+    def timed_variant(make_step):
+        for _ in range(max(args.warmup, 1)):
+            make_step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            make_step()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t1
+
+    extras = world == 1 and not shard and not args.unfused and not args.train_step
+    f32_mode = None
+    if extras and args.mlp_mode != "f32" and not args.no_f32:
+        dt = timed_variant(lambda: bound_step(99, mode="f32").run())
+        f32_mode = {"workload": "the same step with the exact fp32 MLP arithmetic (v_mfma_f32_16x16x4_f32)",
+                    "value": B * n * args.steps / dt, "unit": "rays/s", "ms_per_step": dt / args.steps * 1e3}
     p24 = None
-    if world == 1 and not shard and not args.unfused and args.origin == "center_fixed" and not args.no_p24:
+    if extras and args.origin == "center_fixed" and not args.no_p24:
         # the same step with the head part added (center+head, P = 24): K timed steps after W warm-up steps, serial
         sc2 = synth.make_scene(S, B, "center+head", args.style_dim, pose_seed=1234, shared_triplane=True)
-        cp2, cb2 = O.register_canonical_pose(sc2["canonical_pose"], sc2["parents"], "center+head")
+        m2 = TriPlaneNARF(synth.nerf_config(origin_location="center+head", Nc=Nc, Nf=Nf), args.style_dim, 24, parent=sc2["parents"],
+                          num_bone_param=23)
+        m2.register_canonical_pose(sc2["canonical_pose"])
+        cp2, cb2 = m2.canonical_pose.to(dev), m2.canonical_bone_length.to(dev)
         d2 = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in sc2.items()}
         tri2 = sc2["tri_plane"][:1].contiguous().to(dev)
         mlp2 = {k: v.to(dev) for k, v in sc2["mlp"].items()}
-        cp2, cb2 = cp2.to(dev), cb2.to(dev)
         coord2 = d2["image_coord"].reshape(B, 3, n).contiguous()
         f2 = ops.triplane_pack(tri2)
         pa2 = torch.empty(B, sc2["num_parts"], 16, device=dev)
         pk2 = torch.empty(B, ops.mlp_pack_bytes(), dtype=torch.uint8, device=dev)
-
-        def step24():
-            return ops.RenderStep(d2["pose_to_camera"], d2["bone_length"], cb2, d2["z_rend"], mlp2, sc2["parents"], "center+head",
-                                  3.0, coord2, d2["inv_intrinsics"], cp2, tri2, f2, Nc, Nf, parts_out=pa2, pack_out=pk2,
-                                  relayout=not args.cache_triplane, seed=99, mlp_mode=args.mlp_mode, want_fine=True,
-                                  early_stop_eps=args.early_stop_eps).run()
-        for _ in range(max(args.warmup, 1)):
-            step24()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            step24()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t1
+        dt = timed_variant(lambda: ops.RenderStep(d2["pose_to_camera"], d2["bone_length"], cb2, d2["z_rend"], mlp2, sc2["parents"],
+                                                  "center+head", 3.0, coord2, d2["inv_intrinsics"], cp2, tri2, f2, Nc, Nf,
+                                                  parts_out=pa2, pack_out=pk2, relayout=not args.cache_triplane, seed=99,
+                                                  mlp_mode=args.mlp_mode, want_fine=True,
+                                                  early_stop_eps=args.early_stop_eps).run())
         p24 = {"workload": f"the same step with origin_location center+head (P = {sc2['num_parts']})", "value": B * n * args.steps / dt,
                "unit": "rays/s", "ms_per_step": dt / args.steps * 1e3}
 
     if rank == 0:
         rays_per_step = B * n_frame if shard else world * B * n
         value = rays_per_step * args.steps / elapsed
-        # SURVEY.md §8(d): V*12*(C+1)*4 gathered texel bytes + each tri-plane once + outputs (+ fine side outputs)
-        alg_bytes = V * 1584 + tri.shape[0] * (96 + 3 * P) * 256 * 256 * 4 + B * n * 20 + B * n * (2 * Nf - 1) * 4
-        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("render_kernel_hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        # SURVEY.md 8(d): V*12*(C+1)*4 gathered texel bytes + each tri-plane once + outputs (+ fine side outputs)
+        gather_bytes = V * 1584
+        compulsory = tri.shape[0] * (96 + 3 * P) * 256 * 256 * 4 + B * n * 20 + B * n * (2 * Nf - 1) * 4
+        t_k = kern_ms * 1e-3
         q = rays_marched * (Nc + Nf - 1)
+        clock_ghz = 2.4
+        l1_peak = NUM_CUS * L1_BYTES_PER_CLK_PER_CU * clock_ghz          # GB/s: what the CUs' texture paths can deliver
+        workload_key = f"C1:{S}:{B}:{Nc}:{Nf}:{P}:{args.mlp_mode}:{int(distinct)}:{args.early_stop_eps}"
+        roof = {
+            # the texel gathers are L1/L2 hits (the tri-plane is read from HBM once): the roofline that bounds the march is
+            # the CUs' vector-memory (texture) path, not HBM. `achieved` = algorithmic texel bytes / kernel time.
+            "bound": "l1-texture-path", "kernel": "enarf::march_kernel",
+            "achieved": gather_bytes / t_k / 1e9, "peak": l1_peak, "unit": "GB/s", "frac": gather_bytes / t_k / 1e9 / l1_peak,
+            "peak_note": f"{NUM_CUS} CUs x {L1_BYTES_PER_CLK_PER_CU:.0f} B/clk x {clock_ghz} GHz (MI355X_MICROARCH.md: 16-B-per-lane loads "
+                         "take 16 clk per wave instruction)",
+            "kernel_ms": kern_ms, "gather_bytes_per_launch": gather_bytes, "compulsory_hbm_bytes_per_launch": compulsory,
+            "hbm_frac_if_every_gather_missed": (gather_bytes + compulsory) / t_k / 1e9 / HBM_PEAK_GBS,
+            "compulsory_hbm_frac": compulsory / t_k / 1e9 / HBM_PEAK_GBS,
+            "valid_part_point_pairs": V, "rays_marched": rays_marched, "mlp_tiles_of_16": tiles,
+            "gather_rounds": rounds, "gather_lane_utilisation": V / max(16 * rounds, 1),
+            "mfma_eligible_tflops": q * 12800 / t_k / 1e12,
+            "mfma_frac_of_bf16_dense_peak": q * 12800 / t_k / 1e12 / BF16_DENSE_TFLOPS,
+            "traffic": None, "counters": None,
+        }
+        prof = counter_fractions(workload_key, kern_ms) if not args.variant else None
+        if prof is not None:          # measured HBM traffic and unit utilisations of THIS workload (rocprofv3, profiles/)
+            roof["traffic"] = prof.get("hbm_bytes_per_launch")
+            roof["counters"] = prof.get("fractions")
+            roof["profiled_kernel_ms"] = prof.get("kernel_ms")
+        mode_label = {"f32": "f32", "f16x3": "f32 (MLP products as 3-term split fp16 on MFMA, fp32 accumulate)",
+                      "bf16x3": "f32 (MLP products as 3-term split bf16 on MFMA)", "bf16": "bf16 MLP operands, fp32 elsewhere"}
+        if args.train_step:
+            step_desc = ("forward (enarf_render_step_fwd) + enarf_render_bwd + enarf_weight_grad + enarf_prepare_bwd"
+                         + (" + all-reduce of the tri-plane and StyledMLP gradients" if world > 1 else ""))
+        elif args.unfused:
+            step_desc = "enarf_prepare + enarf_triplane_pack + enarf_render_fwd"
+        else:
+            step_desc = "enarf_render_step_fwd (pre-march launch: re-layout + prepare + ray set-up; then the march)"
         out = {
             "metric": "rendered rays/sec (128^2, 64 samples/ray, 24 bones)", "value": value, "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong" if shard else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"C1: DSO-style {S}x{S} frame, Nc {Nc} + Nf {Nf} samples/ray, 24 joints -> P={P} parts "
-                                   f"({args.origin}), {B} frame/GPU/step, {'per-frame' if tri.shape[0] > 1 else 'constant'} fp32 tri-plane 256^2x(96+{3 * P}), "
-                                   f"in-kernel Philox importance sampling",
-                       "sharding": "rays of one frame batch across ranks + all-gather of outputs" if shard else "one frame batch per rank",
-                       "library": _lib.library_info(), "spinup_ms": args.spinup_ms, "streams": n_streams, "mlp_arith": args.mlp_mode, "early_stop_eps": args.early_stop_eps, "triplane_relayout_in_step": not args.cache_triplane,
-                       "step": ("enarf_prepare + enarf_triplane_pack + enarf_render_fwd" if args.unfused else
-                                "enarf_render_step_fwd (pre-march launch: re-layout + prepare + ray set-up; then the march)")},
-            "roofline": {"bound": "hbm", "kernel": "enarf::render_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes,
-                         # tri-plane once + outputs: what would have to cross HBM with perfect caching
-                         "compulsory_bytes_per_launch": alg_bytes - V * 1584,
-                         "compulsory_GBps": (alg_bytes - V * 1584) / (kern_ms * 1e-3) / 1e9,
-                         "valid_part_point_pairs": V, "rays_marched": rays_marched, "mlp_tiles_of_16": tiles,
-                         "gather_rounds": rounds, "gather_lane_utilisation": V / max(16 * rounds, 1),
-                         "mfma_eligible_tflops": q * 12800 / (kern_ms * 1e-3) / 1e12,
-                         "mfma_frac_of_bf16_dense_peak": q * 12800 / (kern_ms * 1e-3) / 1e12 / BF16_DENSE_TFLOPS},
+            "higher_is_better": True, "scaling": "strong" if (shard or multi) else "weak", "vs_baseline": None,
+            "dtype": mode_label[args.mlp_mode], "data": "synthetic",
+            "config": {"workload": (f"{'C3 shape: ' + str(world * B) + ' GAN-style' if multi else 'C1: ' + str(B) + ' DSO-style'} "
+                                    f"{S}x{S} frame(s), Nc {Nc} + Nf {Nf} samples/ray, 24 joints -> P={P} parts ({args.origin}), "
+                                    f"{B} frame(s)/GPU/step, {'per-frame' if tri.shape[0] > 1 else 'constant'} fp32 tri-plane "
+                                    f"256^2x(96+{3 * P}), in-kernel Philox importance sampling"),
+                       "sharding": ("rays of one frame batch across ranks + all-gather of outputs" if shard else
+                                    f"a fixed batch of {world * B} frames dealt {B} per rank" if multi else "one frame batch per rank"),
+                       "library": _lib.library_info(), "env": {k: v for k, v in os.environ.items() if k.startswith("ENARF_")},
+                       "spinup_ms": args.spinup_ms, "streams": n_streams, "mlp_arith": args.mlp_mode,
+                       "early_stop_eps": args.early_stop_eps, "triplane_relayout_in_step": not args.cache_triplane,
+                       "step": step_desc},
+            "roofline": roof,
         }
+        if f32_mode is not None:
+            out["f32_mode"] = f32_mode
         if p24 is not None:
             out["p24"] = p24
         if not args.no_cpu_baseline and world == 1:

@@ -141,6 +141,10 @@ SIGNATURES = {
                                             C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "enarf_triplane_sample_bwd": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int,
                                             C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "enarf_triplane_sample_ex_fwd": (C.c_int, [_f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_longlong,
+                                               C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "enarf_triplane_sample_ex_bwd": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                               C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "enarf_triplane_pack": (C.c_int, [_f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "enarf_mlp_pack_bytes": (C.c_size_t, []),
     "enarf_prepare": (C.c_int, [C.POINTER(PrepareArgs), C.c_void_p]),

@@ -1,6 +1,6 @@
 // enarf_render.hip - prepare, point-cloud query and the fused ray-march kernels + their C-ABI entry points.
 // gfx950 only. See include/enarf_hip.h for the contract and DESIGN.md for the kernel design.
-#include "enarf_march.h"
+#include "enarf_tasks.h"
 #include "enarf_host.h"
 
 #ifndef ENARF_S2_PRIO
@@ -512,7 +512,6 @@ __global__ __launch_bounds__(256) void pre_march_kernel(const PreParams q) {
 }
 
 // scratch layout (floats) of the render kernel; up to kMaxSamples samples per pass
-constexpr int kMaxSamples = 128;
 constexpr int SC_BTAB = 0;        // Nc + 1 bin edges (<= 129)
 constexpr int SC_CAND = 136;      // 4 waves x 32 ints
 constexpr int SC_CH = 264;        // coarse: sigma head [128]
@@ -1002,8 +1001,49 @@ int device_cus() {
 }
 }  // namespace enarf
 
+#ifndef ENARF_TASK_MARCH            // 1: the tile-task march (enarf_tasks.h); 0: the round-1 workgroup-per-ray march (A/B builds)
+#define ENARF_TASK_MARCH 1
+#endif
+#ifndef ENARF_TASK_WAVES
+#define ENARF_TASK_WAVES 12
+#endif
+#ifndef ENARF_TASK_SLOTS
+#define ENARF_TASK_SLOTS 8
+#endif
+
+template <int MODE, int SPL>
+static int launch_task_march(const enarf_render_args &a, hipStream_t st, bool with_setup) {
+    constexpr int NW = ENARF_TASK_WAVES;
+    const int num_cus = device_cus();
+    if (num_cus <= 0) return host::fail((int)hipGetLastError(), "enarf_render_fwd: cannot query the device");
+    const long long total = (long long)a.B * a.n;
+    // rays in flight per workgroup: enough tiles for every wave (3-4 per ray and stage), never more than there are rays
+    int nslots = ENARF_TASK_SLOTS;
+    long long wgs = num_cus;
+    if (wgs * nslots > total) {          // few rays: spread them over the CUs first
+        nslots = (int)((total + wgs - 1) / wgs);
+        if (nslots < 1) nslots = 1;
+        wgs = (total + nslots - 1) / nslots;
+    }
+    const size_t lds = (size_t)tasks_lds_floats<MODE>(a.P, nslots) * 4;
+    auto kern = march_kernel<MODE, SPL, NW>;
+    static bool attr_set = false;        // per instantiation: allow more than the default 64 KB of dynamic LDS
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return host::fail((int)e, "enarf_render_fwd: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    if (with_setup)
+        if (int rc = launch_ray_setup(a, st)) return rc;
+    hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(NW * 64), lds, st, a, nslots);
+    return host::check_launch("enarf_render_fwd");
+}
+
 template <int MODE, int SPL>
 static int launch_render(const enarf_render_args &a, hipStream_t st, bool with_setup) {
+#if ENARF_TASK_MARCH
+    return launch_task_march<MODE, SPL>(a, st, with_setup);
+#endif
     // persistent grid: as many workgroups as stay resident (3 per CU at <= 168 VGPRs and ~37 KB LDS), never more
     // than there are rays
     const int num_cus = device_cus();

@@ -87,17 +87,20 @@ __global__ __launch_bounds__(256) void pack_kernel(const float *__restrict__ in,
 }
 
 // ---- direct NCHW forward: thread per point, channel loop outermost (no global read-modify-write) -------
+// `separate`: the three planes' samples are written side by side, out (B, 3, C, n), instead of summed (the callers of
+// sample_feature's "prod" reduction need them apart, sampling.py:43-48). `point_image`: per-point image index (then the grid
+// has batch 1): the semantics of sample_feature's batch_idx without its side-by-side copy of the planes (sampling.py:34-38).
 __global__ __launch_bounds__(256) void sample_fwd_direct(const float *__restrict__ in, const float *__restrict__ grid,
                                                          float *__restrict__ out, int C, int H, int W, long long n,
-                                                         SamplerCfg cfg) {
+                                                         SamplerCfg cfg, int separate, const int *__restrict__ point_image) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     const int b = blockIdx.y;
     if (i >= n) return;
     const float *g = grid + ((size_t)b * n + i) * 3;
     const float c3[3] = {g[0], g[1], g[2]};
     const size_t hw = (size_t)H * W;
-    const float *inb = in + (size_t)b * 3 * C * hw;
-    float *ob = out + (size_t)b * C * n + i;
+    const float *inb = in + (size_t)(point_image ? point_image[i] : b) * 3 * C * hw;
+    float *ob = out + (size_t)b * (separate ? 3 : 1) * C * n + i;
     if (cfg.interp == ENARF_INTERP_BILINEAR) {
         Tap2D t[3];
 #pragma unroll
@@ -114,9 +117,10 @@ __global__ __launch_bounds__(256) void sample_fwd_direct(const float *__restrict
                 s += pl[t[p].o[1]] * t[p].w[1];
                 s += pl[t[p].o[2]] * t[p].w[2];
                 s += pl[t[p].o[3]] * t[p].w[3];
+                if (separate) ob[((size_t)p * C + c) * n] = s;
                 acc += s;
             }
-            ob[(size_t)c * n] = acc;
+            if (!separate) ob[(size_t)c * n] = acc;
         }
     } else {   // nearest: the reference overwrites per plane, so the last plane (zx) wins (kernel.cu:76-90)
         float gm;
@@ -124,7 +128,9 @@ __global__ __launch_bounds__(256) void sample_fwd_direct(const float *__restrict
         const int yi = (int)roundf(gs_source_index(c3[0], H, cfg, gm));
         const bool ok = (xi >= 0) & (xi < W) & (yi >= 0) & (yi < H);
         for (int c = 0; c < C; ++c)
-            ob[(size_t)c * n] = ok ? inb[((size_t)2 * C + c) * hw + (size_t)yi * W + xi] : 0.0f;
+            ob[(size_t)((separate ? 2 * C : 0) + c) * n] = ok ? inb[((size_t)2 * C + c) * hw + (size_t)yi * W + xi] : 0.0f;
+        if (separate)
+            for (int c = 0; c < 2 * C; ++c) ob[(size_t)c * n] = 0.0f;
     }
 }
 
@@ -165,16 +171,17 @@ __global__ __launch_bounds__(256) void sample_fwd_cl(const float *__restrict__ c
 __global__ __launch_bounds__(256) void sample_bwd_direct(const float *__restrict__ gout, const float *__restrict__ in,
                                                          const float *__restrict__ grid, float *__restrict__ gin,
                                                          float *__restrict__ ggrid, int C, int H, int W, long long n,
-                                                         SamplerCfg cfg) {
+                                                         SamplerCfg cfg, int separate, const int *__restrict__ point_image) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     const int b = blockIdx.y;
     if (i >= n) return;
     const float *g = grid + ((size_t)b * n + i) * 3;
     const float c3[3] = {g[0], g[1], g[2]};
     const size_t hw = (size_t)H * W;
-    const float *inb = in + (size_t)b * 3 * C * hw;
-    float *ginb = gin ? gin + (size_t)b * 3 * C * hw : nullptr;
-    const float *go = gout + (size_t)b * C * n + i;
+    const int bi = point_image ? point_image[i] : b;
+    const float *inb = in + (size_t)bi * 3 * C * hw;
+    float *ginb = gin ? gin + (size_t)bi * 3 * C * hw : nullptr;
+    const float *go = gout + (size_t)b * (separate ? 3 : 1) * C * n + i;
     float gg[3] = {0.0f, 0.0f, 0.0f};
     if (cfg.interp == ENARF_INTERP_BILINEAR) {
 #pragma unroll
@@ -186,7 +193,7 @@ __global__ __launch_bounds__(256) void sample_bwd_direct(const float *__restrict
             const float ax1 = ix - t.fx, ax0 = (t.fx + 1.0f) - ix, ay1 = iy - t.fy, ay0 = (t.fy + 1.0f) - iy;
             float gix = 0.0f, giy = 0.0f;
             for (int c = 0; c < C; ++c) {
-                const float gO = go[(size_t)c * n];
+                const float gO = go[(size_t)((separate ? p * C : 0) + c) * n];
                 const size_t po = ((size_t)p * C + c) * hw;
                 if (ginb) {
 #pragma unroll
@@ -210,7 +217,7 @@ __global__ __launch_bounds__(256) void sample_bwd_direct(const float *__restrict
         const int yi = (int)roundf(gs_source_index(c3[0], H, cfg, gm));
         if ((xi >= 0) & (xi < W) & (yi >= 0) & (yi < H))
             for (int c = 0; c < C; ++c)
-                atomicAdd(ginb + ((size_t)2 * C + c) * hw + (size_t)yi * W + xi, go[(size_t)c * n]);
+                atomicAdd(ginb + ((size_t)2 * C + c) * hw + (size_t)yi * W + xi, go[(size_t)((separate ? 2 * C : 0) + c) * n]);
     }
     if (ggrid) {
         float *o = ggrid + ((size_t)b * n + i) * 3;
@@ -442,8 +449,41 @@ extern "C" int enarf_triplane_sample_fwd(const float *input, const float *grid, 
         return host::check_launch("enarf_triplane_sample_fwd");
     }
     hipLaunchKernelGGL(sample_fwd_direct, dim3((unsigned)((n_pts + 255) / 256), B), dim3(256), 0, st, input, grid, out,
-                       C, H, W, n_pts, cfg);
+                       C, H, W, n_pts, cfg, 0, (const int *)nullptr);
     return host::check_launch("enarf_triplane_sample_fwd");
+}
+
+static int check_ex(const char *who, int B, int n_images, const int *point_image, int reduction) {
+    if (reduction != ENARF_PLANES_SUM && reduction != ENARF_PLANES_SEPARATE) return host::fail(ENARF_ERR_ARG, "%s: bad plane reduction %d", who, reduction);
+    if (n_images <= 0 || n_images > 65535) return host::fail(ENARF_ERR_ARG, "%s: bad n_images %d", who, n_images);
+    if (point_image && B != 1) return host::fail(ENARF_ERR_ARG, "%s: point_image needs a grid of batch 1 (got %d)", who, B);
+    if (!point_image && n_images != B) return host::fail(ENARF_ERR_ARG, "%s: n_images %d != B %d without point_image", who, n_images, B);
+    return 0;
+}
+
+extern "C" int enarf_triplane_sample_ex_fwd(const float *input, const float *grid, float *out, int B, int C, int H, int W,
+                                            long long n_pts, int interp, int pad, int align_corners, int reduction,
+                                            const int *point_image, int n_images, enarf_stream_t stream) {
+    if (int rc = check_sampler("enarf_triplane_sample_ex_fwd", input, grid, out, B, C, H, W, n_pts, interp, pad)) return rc;
+    if (int rc = check_ex("enarf_triplane_sample_ex_fwd", B, n_images, point_image, reduction)) return rc;
+    if (n_pts == 0) return 0;
+    const SamplerCfg cfg{interp, pad, align_corners ? 1 : 0};
+    hipLaunchKernelGGL(sample_fwd_direct, dim3((unsigned)((n_pts + 255) / 256), B), dim3(256), 0, (hipStream_t)stream, input, grid,
+                       out, C, H, W, n_pts, cfg, reduction == ENARF_PLANES_SEPARATE ? 1 : 0, point_image);
+    return host::check_launch("enarf_triplane_sample_ex_fwd");
+}
+
+extern "C" int enarf_triplane_sample_ex_bwd(const float *grad_out, const float *input, const float *grid, float *grad_input,
+                                            float *grad_grid, int B, int C, int H, int W, long long n_pts, int interp, int pad,
+                                            int align_corners, int reduction, const int *point_image, int n_images,
+                                            enarf_stream_t stream) {
+    if (int rc = check_sampler("enarf_triplane_sample_ex_bwd", grad_out, input, grid, B, C, H, W, n_pts, interp, pad)) return rc;
+    if (int rc = check_ex("enarf_triplane_sample_ex_bwd", B, n_images, point_image, reduction)) return rc;
+    if (n_pts == 0 || (!grad_input && !grad_grid)) return 0;
+    const SamplerCfg cfg{interp, pad, align_corners ? 1 : 0};
+    hipLaunchKernelGGL(sample_bwd_direct, dim3((unsigned)((n_pts + 255) / 256), B), dim3(256), 0, (hipStream_t)stream, grad_out,
+                       input, grid, grad_input, grad_grid, C, H, W, n_pts, cfg, reduction == ENARF_PLANES_SEPARATE ? 1 : 0, point_image);
+    return host::check_launch("enarf_triplane_sample_ex_bwd");
 }
 
 extern "C" int enarf_triplane_sample_bwd(const float *grad_out, const float *input, const float *grid, float *grad_input,
@@ -467,7 +507,7 @@ extern "C" int enarf_triplane_sample_bwd(const float *grad_out, const float *inp
         return grad_input ? enarf_triplane_unpack_add(gcl, grad_input, B, 3 * C, H, W, stream) : 0;
     }
     hipLaunchKernelGGL(sample_bwd_direct, dim3((unsigned)((n_pts + 255) / 256), B), dim3(256), 0, (hipStream_t)stream,
-                       grad_out, input, grid, grad_input, grad_grid, C, H, W, n_pts, cfg);
+                       grad_out, input, grid, grad_input, grad_grid, C, H, W, n_pts, cfg, 0, (const int *)nullptr);
     return host::check_launch("enarf_triplane_sample_bwd");
 }
 

@@ -18,17 +18,18 @@ GRID_SAMPLE_PADDING_MODES = {"zeros": 0, "border": 1, "reflection": 2}
 
 
 def _forward(input, grid, interpolation_mode, padding_mode, align_corners):
-    return ops.triplane_sample_fwd(input, grid, int(interpolation_mode), int(padding_mode), bool(align_corners))
+    # the reference dispatches float / double / half and returns `input.new_zeros(...)`, i.e. the INPUT's dtype
+    # (TriplaneSampler_kernel.cu:244, TriplaneSampler.cpp:20); the HIP kernels compute in fp32
+    out = ops.triplane_sample_fwd(input, grid, int(interpolation_mode), int(padding_mode), bool(align_corners))
+    return out.to(input.dtype)
 
 
 def _backward(grad_output, input, grid, interpolation_mode, padding_mode, align_corners, output_mask):
     gi, gg = ops.triplane_sample_bwd(grad_output, input, grid, int(interpolation_mode), int(padding_mode),
                                      bool(align_corners), bool(output_mask[0]), bool(output_mask[1]))
     # the pybind module returns placeholder tensors where a gradient is not needed (TriplaneSampler.cpp:37,:44)
-    if gi is None:
-        gi = input.new_zeros((1, 1, 1, 1))
-    if gg is None:
-        gg = torch.zeros((0, 0, 0, 0))
+    gi = input.new_zeros((1, 1, 1, 1)) if gi is None else gi.to(input.dtype)
+    gg = torch.zeros((0, 0, 0, 0)) if gg is None else gg.to(grid.dtype)
     return gi, gg
 
 
@@ -55,6 +56,8 @@ class TriplaneSamplerFunction(torch.autograd.Function):
         need_g = bool(ctx.output_mask[1]) and ctx.needs_input_grad[1]
         gi, gg = ops.triplane_sample_bwd(grad_output, input, grid, ctx.mode_enum, ctx.padding_mode_enum,
                                          ctx.align_corners, need_i, need_g)
+        gi = None if gi is None else gi.to(input.dtype)
+        gg = None if gg is None else gg.to(grid.dtype)
         return gi, gg, None, None, None, None
 
 

@@ -116,6 +116,39 @@ def triplane_sample_bwd(grad_out: torch.Tensor, inp: torch.Tensor, grid: torch.T
     return gi, gg
 
 
+@_on_tensor_device
+def triplane_sample_ex_fwd(inp: torch.Tensor, grid: torch.Tensor, separate: bool = False,
+                           point_image: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Generalised gather (bilinear, zeros, align_corners False): input (Bimg, 3C, H, W), grid (B, n, 3) -> (B, C, n), or
+    (B, 3, C, n) with `separate` (the planes' samples side by side). point_image (n,) int32 with B == 1: point i samples
+    image point_image[i]."""
+    lib = _lib.load()
+    inp, grid = _dev_f32(inp, "input"), _dev_f32(grid, "grid")
+    Bi, C3, H, W = inp.shape
+    B, n, _ = grid.shape
+    Cc = C3 // 3
+    pi = None if point_image is None else point_image.to(device=inp.device, dtype=torch.int32).contiguous()
+    out = torch.empty((B, 3, Cc, n) if separate else (B, Cc, n), dtype=torch.float32, device=inp.device)
+    _lib.check(lib.enarf_triplane_sample_ex_fwd(_p(inp), _p(grid), _p(out), B, Cc, H, W, n, 0, 0, 0, int(separate), _p(pi), Bi,
+                                                _stream(inp.device)), "enarf_triplane_sample_ex_fwd")
+    return out
+
+
+@_on_tensor_device
+def triplane_sample_ex_bwd(grad_out: torch.Tensor, inp: torch.Tensor, grid: torch.Tensor, separate: bool,
+                           point_image: Optional[torch.Tensor], need_input: bool, need_grid: bool):
+    lib = _lib.load()
+    go, inp, grid = _dev_f32(grad_out, "grad_output"), _dev_f32(inp, "input"), _dev_f32(grid, "grid")
+    Bi, C3, H, W = inp.shape
+    B, n, _ = grid.shape
+    pi = None if point_image is None else point_image.to(device=inp.device, dtype=torch.int32).contiguous()
+    gi = torch.zeros_like(inp) if need_input else None
+    gg = torch.empty_like(grid) if need_grid else None
+    _lib.check(lib.enarf_triplane_sample_ex_bwd(_p(go), _p(inp), _p(grid), _p(gi), _p(gg), B, C3 // 3, H, W, n, 0, 0, 0,
+                                                int(separate), _p(pi), Bi, _stream(inp.device)), "enarf_triplane_sample_ex_bwd")
+    return gi, gg
+
+
 # ---------------------------------------------------------------------------------------- a16 ray sampler
 @_on_tensor_device
 def mask_dilate_topk(mask: torch.Tensor, noise: torch.Tensor, k: int, radius: int = 64) -> torch.Tensor:

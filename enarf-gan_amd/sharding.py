@@ -29,13 +29,17 @@ def rays_for_rank(num_rays: int, rank: int, world: int) -> slice:
     return slice(*split_range(num_rays, rank, world))
 
 
-def near_far_inputs_are_global(pose_to_camera: torch.Tensor) -> torch.Tensor:
-    """The reference's near/far planes are min/max over the WHOLE batch of part centres (rendering.py:15-17).
-    When frames of one logical batch are sharded, every rank must therefore hand the kernel the full batch of
-    part frames for that reduction; this helper only documents and checks that contract."""
-    if pose_to_camera.dim() != 4:
-        raise ValueError("pose_to_camera must be (B, J, 4, 4)")
-    return pose_to_camera
+def batch_share(global_frames: int, rank: int, world: int) -> Tuple[int, int]:
+    """(first frame, frames) of `rank` when a FIXED batch of `global_frames` frames is dealt evenly (bench.py N > 1: the C3
+    batch of 64 frames -> 64 / N per rank). The reference's batch-global near / far planes (rendering.py:15-17) are then
+    per rank-local batch - exactly what DistributedDataParallel does to the reference: every replica renders its own
+    mini-batch with its own planes - so ranks exchange nothing in the forward."""
+    if global_frames % world:
+        raise ValueError(f"{global_frames} frames do not divide over {world} ranks")
+    per = global_frames // world
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} outside world {world}")
+    return rank * per, per
 
 
 def all_gather_rays(local: torch.Tensor, num_rays: int, group=None) -> torch.Tensor:

@@ -231,3 +231,20 @@ def make_scene(size: int, batch: int, origin_location: str = "center_fixed", sty
         "tri_plane": tri, "mlp": make_mlp_params(style_dim, mlp_seed),
         "z_rend": make_z_rend(batch, style_dim, z_seed), "coordinate_scale": 3.0,
     }
+
+
+class AttrDict(dict):
+    """dict with attribute access: stands in for the reference's EasyDict configs (libraries/config.py)"""
+    __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__
+
+
+def nerf_config(**overrides) -> AttrDict:
+    """`nerf_params` with the keys the render path reads and the shipping defaults
+    (configs/enarfgan_train/SURREAL/config.yml:15-21, configs/DSO_demo/default.yml:16-34)."""
+    c = AttrDict(hidden_size=32, Nc=48, Nf=64, origin_location="center_fixed", coordinate_scale=3, render_bs=16384,
+                 no_ray_direction=True, multiply_density_with_triplane_wieght=False, clamp_mask=False, constant_triplane=True,
+                 constant_trimask=False, constant_trimask_lr_mul=1, deformation_field=False, selector_mlp=False,
+                 no_selector=False, time_conditional=True, pose_conditional=False)
+    c.update(overrides)
+    return c

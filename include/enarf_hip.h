@@ -80,6 +80,24 @@ int enarf_triplane_sample_bwd(const float *grad_out, const float *input, const f
                               int interpolation_mode, int padding_mode, int align_corners,
                               void *workspace, enarf_stream_t stream);
 
+/* The same gather for the rest of libraries/triplane/sampling.py's API surface (sample_feature with reduction "prod",
+ * with batch_idx; sample_triplane_part_prob; sample_weighted_feature_v2), which the fused kernels make unnecessary on the
+ * render path but callers of the reference API may use stand-alone:
+ *   reduction   ENARF_PLANES_SUM: out (B, C, n) as above; ENARF_PLANES_SEPARATE: out (B, 3, C, n), the planes' samples
+ *               side by side (the caller applies sigmoid / product / clamp, sampling.py:43-48);
+ *   point_image NULL, or device (n_pts,) int32 with a grid of batch 1: point i samples image point_image[i] of `input`
+ *               (n_images of them) - sample_feature's batch_idx (sampling.py:34-38) without the side-by-side plane copy.
+ * The backward is the true gradient (grad_input zero-filled by the caller, shape of input; either may be NULL). */
+#define ENARF_PLANES_SUM      0
+#define ENARF_PLANES_SEPARATE 1
+int enarf_triplane_sample_ex_fwd(const float *input, const float *grid, float *out, int B, int C, int H, int W,
+                                 long long n_pts, int interpolation_mode, int padding_mode, int align_corners,
+                                 int reduction, const int *point_image, int n_images, enarf_stream_t stream);
+int enarf_triplane_sample_ex_bwd(const float *grad_out, const float *input, const float *grid, float *grad_input,
+                                 float *grad_grid, int B, int C, int H, int W, long long n_pts, int interpolation_mode,
+                                 int padding_mode, int align_corners, int reduction, const int *point_image, int n_images,
+                                 enarf_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Tri-plane re-layout. The renderer reads the 96 feature channels channel-last,
  *   feat_cl[b][plane][y][x][32]   (one texel = 128 B = one cache line),

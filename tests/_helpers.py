@@ -40,19 +40,28 @@ def u8_mismatches(ours_f32, ref_f32):
     return [(int(i), float(a[i]), float(b[i])) for i in bad]
 
 
-def assert_u8_mask_matches(ours_f32, ref_f32, what, max_float_gap=1e-5, max_frac=0.02):
+def assert_u8_mask_matches(ours_f32, ref_f32, what, max_float_gap=1e-5, max_frac=2e-3):
     """The integer foreground mask, (mask * 255).astype(uint8) (ENARF_GAN_demo.py:79), against the reference's: equal on
-    EVERY pixel except true straddlers of a quantisation step - listed with both float values - i.e. pixels whose two
-    float masks differ by less than `max_float_gap` (10x tighter than the 1e-4 parity bound) and truncate to adjacent
-    integers. The truncating quantiser has a step at exactly 1.0, where the opaque pixels of a body sit (sum of weights =
-    1 - T_end with T_end ~ 1e-8): there a last-bit difference in the float sum flips 255 <-> 254, for the reference against
-    itself on another BLAS as much as for us. Returns the list; more than `max_frac` of the pixels is a failure."""
+    EVERY pixel except true straddlers of a quantisation step - returned as [(index, ours, reference)] - i.e. pixels whose
+    two float masks differ by less than `max_float_gap` (10x tighter than the 1e-4 parity bound) and truncate to ADJACENT
+    integers. Two kinds:
+      * the saturation step 254 | 255: an opaque pixel's mask is 1 - T_end with T_end ~ 1e-8, i.e. 1.0 to the last bit or
+        two, and the truncating quantiser steps exactly at 1.0; which side a pixel lands on is decided by the rounding of
+        a 63-term float sum (the reference against itself on another BLAS or thread count flips them as well). Any
+        number of these is accepted, each within 3 ulp of 1.0 on both sides;
+      * everywhere else at most `max_frac` of the pixels (with errors ~1e-6 and 255 steps that is the expected count)."""
     bad = u8_mismatches(ours_f32, ref_f32)
+    away = []
     for i, a, b in bad:
-        assert abs(a - b) <= max_float_gap and abs(int(np.float32(a) * np.float32(255)) - int(np.float32(b) * np.float32(255))) == 1, \
+        qa, qb = int(np.float32(a) * np.float32(255)), int(np.float32(b) * np.float32(255))
+        assert abs(a - b) <= max_float_gap and abs(qa - qb) == 1, \
             f"{what}: pixel {i} differs in the integer mask and is not a straddler: ours {a!r} reference {b!r}"
+        if {qa, qb} == {254, 255}:
+            assert abs(a - 1.0) <= 4e-7 and abs(b - 1.0) <= 4e-7, f"{what}: pixel {i}: {a!r} vs {b!r} at the saturation step"
+        else:
+            away.append((i, a, b))
     n = np.asarray(ref_f32).size
-    assert len(bad) <= max_frac * n, f"{what}: {len(bad)} of {n} pixels straddle a step: {bad[:20]}"
+    assert len(away) <= max(3, max_frac * n), f"{what}: {len(away)} of {n} pixels straddle a step below saturation: {away[:20]}"
     return bad
 
 

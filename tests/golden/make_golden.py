@@ -319,6 +319,45 @@ def run_encoding_case(name, seed):
     print(f"{name}: masked channels {int((out['enc_length'] == 0).sum())} -> {os.path.getsize(path) / 1024:.0f} KiB")
 
 
+def run_sampling_case(name, seed):
+    """libraries/triplane/sampling.py:9-127 stand-alone: sample_feature (sum, prod with and without clamp_mask, the
+    batch_idx side-by-side form), sample_triplane_part_prob (prod / sum / uniform) and sample_weighted_feature_v2, with the
+    reference's own autograd gradients for the latter."""
+    import torch.nn.functional as F
+    from libraries.triplane.sampling import sample_feature, sample_triplane_part_prob, sample_weighted_feature_v2
+    g = torch.Generator().manual_seed(seed)
+    B, P, h, n = 2, 3, 16, 150
+    planes = torch.randn(B, 3 * 4, h, h, generator=g)
+    pos = torch.rand(B, 3, n, generator=g) * 2.4 - 1.2
+    out_sum = sample_feature(planes, pos)                                   # B = 2: the F.grid_sample branch
+    wplanes = torch.randn(B * P, 3, h, h, generator=g) * 3.0
+    ppos = torch.rand(B, P, 3, n, generator=g) * 2.2 - 1.1
+    valid = torch.rand(B, P, n, generator=g) > 0.4
+    masked = ppos * valid[:, :, None] + 2 * ~valid[:, :, None]              # models/narf.py:237
+    prob_prod = sample_triplane_part_prob(wplanes, masked, valid)
+    prob_clamp = sample_triplane_part_prob(wplanes, masked, valid, clamp_mask=True)
+    prob_sum = sample_triplane_part_prob(wplanes, masked, valid, mode="sum")
+    prob_uni = sample_triplane_part_prob(wplanes, masked, valid, mode="none")
+    # batch_idx form on the side-by-side plane (sampling.py:96-97 builds it like this)
+    feat = torch.randn(B, 96, h, h, generator=g).requires_grad_(True)
+    padded = F.pad(feat, (0, 1)).permute(1, 2, 0, 3).reshape(1, 96, h, (h + 1) * B)
+    bidx = torch.randint(0, B, (n,), generator=g)
+    pos1 = (torch.rand(1, 3, n, generator=g) * 2.0 - 1.0)
+    out_bidx = sample_feature(padded, pos1.clone(), batch_idx=bidx)
+    weight = torch.rand(B, P, n, generator=g).requires_grad_(True)
+    wf = sample_weighted_feature_v2(32, feat, masked, weight, valid)
+    cot = torch.randn(wf.shape, generator=g)
+    g_feat, g_weight = torch.autograd.grad(wf, (feat, weight), cot)
+    out = dict(planes=planes.numpy(), pos=pos.numpy(), out_sum=out_sum.numpy(), wplanes=wplanes.numpy(), masked=masked.numpy(),
+               valid=valid.numpy(), prob_prod=prob_prod.numpy(), prob_clamp=prob_clamp.numpy(), prob_sum=prob_sum.numpy(),
+               prob_uni=prob_uni.numpy(), feat=feat.detach().numpy(), bidx=bidx.numpy().astype(np.int32),
+               pos1=pos1.numpy(), out_bidx=out_bidx.detach().numpy(), weight=weight.detach().numpy(), wf=wf.detach().numpy(),
+               cot=cot.numpy(), g_feat=g_feat.numpy(), g_weight=g_weight.numpy())
+    path = os.path.join(HERE, f"{name}.npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: valid pairs {int(valid.sum())} -> {os.path.getsize(path) / 1024:.0f} KiB")
+
+
 def run_query_case(name, batch, n_points, origin_location, style_dim, seed):
     """calc_density_and_color_from_camera_coord_v2 (models/narf.py:176) on a point cloud."""
     from enarf_gan_amd import synth
@@ -429,6 +468,9 @@ def main():
         run_render_case("render_c4s_32_b2", size=32, batch=2, Nc=72, Nf=96, origin_location="center_fixed",
                         style_dim=256, n_keep=96, seed=25)
         return
+    if "--only-sampling" in sys.argv:
+        run_sampling_case("sampling_api", seed=51)
+        return
     if "--only-encoding" in sys.argv:
         run_encoding_case("encoding", seed=41)
         return
@@ -462,6 +504,7 @@ def main():
     run_fullframe_case("full_c1_128_b1_p23", size=128, batch=1, Nc=48, Nf=64, origin_location="center_fixed", style_dim=20)
     run_fullframe_case("full_gan_32_b2", size=32, batch=2, Nc=48, Nf=64, origin_location="center_fixed", style_dim=256)
     run_encoding_case("encoding", seed=41)
+    run_sampling_case("sampling_api", seed=51)
 
 
 if __name__ == "__main__":

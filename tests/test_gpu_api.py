@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 import torch
 
-from _helpers import Scene, assert_close, load_golden
+from _helpers import Scene, assert_close, load_golden, rel_err
 from oracle import enarf_oracle as O
 from test_host_cpu import Cfg, _nerf_cfg
 
@@ -160,10 +160,12 @@ def test_mask_based_sampler_matches_torch(B, h, w, k, r):
         assert len(set(t[b].tolist())) == k
         thr = torch.topk(dil[b], k)[0][-1]
         assert bool((dil[b][t[b]] >= thr).all())
-    # the entry point with the reference's signature
+    # the entry point with the reference's signature (its window is fixed: 129 x 129)
     idx, homo = mask_based_sampler(mask.cuda(), k, noise=noise.cuda())
-    assert sorted(idx[0].cpu().tolist()) == sorted(ref[0].tolist())
-    assert torch.equal(homo[0, 0, 0].cpu(), (idx[0].cpu() % w).float() + 0.5) and homo.shape == (B, 1, 3, k)
+    if r == 64:
+        assert sorted(idx[0].cpu().tolist()) == sorted(ref[0].tolist())
+    assert idx.shape == (B, k) and idx.dtype == torch.int64 and homo.shape == (B, 1, 3, k)
+    assert torch.equal(homo[0, 0, 0].cpu(), (idx[0].cpu() % w).float() + 0.5)
     assert torch.equal(homo[0, 0, 1].cpu(), torch.div(idx[0].cpu(), w, rounding_mode="floor").float() + 0.5)
 
 
@@ -207,6 +209,41 @@ def test_gan_generator_forward_matches_oracle():
     with torch.no_grad():
         fgc, fgm, bg = gen(s["pose_to_camera"].cuda(), None, s["bone_length"].cuda(), z, s["inv_intrinsics"].cuda(), return_bg=True)
     assert bg == -1 and fgc.shape == (B, 3, S, S)
+
+
+def test_sampling_api_mirror_matches_reference_golden():
+    """libraries/triplane/sampling.py mirror (sample_feature: sum / prod / clamp_mask / batch_idx, sample_triplane_part_prob:
+    prod / sum-softmax / uniform, sample_weighted_feature_v2 with gradients) against values and autograd gradients recorded
+    from the reference's own functions (tests/golden/sampling_api.npz)."""
+    import torch.nn.functional as F
+    from enarf_gan_amd.libraries.triplane.sampling import sample_feature, sample_triplane_part_prob, sample_weighted_feature_v2
+    g = load_golden("sampling_api")
+    t = lambda k: torch.from_numpy(g[k]).cuda()
+    assert_close(sample_feature(t("planes"), t("pos")).cpu(), g["out_sum"], "sample_feature sum, B = 2", 1e-5)
+    valid = t("valid")
+    assert_close(sample_triplane_part_prob(t("wplanes"), t("masked"), valid).cpu(), g["prob_prod"], "part prob prod", 1e-5)
+    assert_close(sample_triplane_part_prob(t("wplanes"), t("masked"), valid, clamp_mask=True).cpu(), g["prob_clamp"], "prob clamp_mask", 1e-5)
+    assert not np.allclose(g["prob_clamp"], g["prob_prod"])
+    assert_close(sample_triplane_part_prob(t("wplanes"), t("masked"), valid, mode="sum").cpu(), g["prob_sum"], "prob sum + softmax", 1e-5)
+    assert torch.equal(sample_triplane_part_prob(t("wplanes"), t("masked"), valid, mode="none").cpu(), torch.from_numpy(g["prob_uni"]))
+    # batch_idx: the reference's side-by-side plane as input
+    feat = t("feat")
+    B, h = feat.shape[0], feat.shape[2]
+    padded = F.pad(feat, (0, 1)).permute(1, 2, 0, 3).reshape(1, 96, h, (h + 1) * B)
+    out = sample_feature(padded, t("pos1"), batch_idx=torch.from_numpy(g["bidx"]).cuda())
+    assert_close(out.cpu(), g["out_bidx"], "sample_feature with batch_idx", 1e-5)
+    # weighted feature, forward and the two gradients
+    f, w = feat.clone().requires_grad_(True), t("weight").requires_grad_(True)
+    wf = sample_weighted_feature_v2(32, f, t("masked"), w, valid)
+    assert_close(wf.detach().cpu(), g["wf"], "sample_weighted_feature_v2", 1e-5)
+    wf.backward(t("cot"))
+    assert_close(f.grad.cpu(), g["g_feat"], "d / d tri-plane features", 1e-5)
+    assert_close(w.grad.cpu(), g["g_weight"], "d / d weight", 1e-5)
+    # dtypes: computed in fp32, returned in the input's dtype (TriplaneSampler.cpp:20)
+    for dt in (torch.float16, torch.float64):
+        o = sample_feature(t("planes")[:1].to(dt), t("pos")[:1].to(dt))
+        assert o.dtype == dt and rel_err(o.float().cpu(), g["out_sum"][:1]).max() < (2e-3 if dt == torch.float16 else 1e-5)
+    assert sample_feature(t("wplanes").half(), t("masked").reshape(6, 3, -1).half(), reduction="prod").dtype == torch.float16
 
 
 def test_sampler_autograd_function_gives_true_gradients():

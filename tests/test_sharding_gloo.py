@@ -56,6 +56,11 @@ def test_split_range_properties():
     with pytest.raises(ValueError):
         sharding.split_range(4, 2, 2)
     assert list(sharding.frames_for_rank(10, 1, 4)) == [3, 4, 5]
+    # bench.py N > 1: the fixed C3 batch of 64 frames
+    assert [sharding.batch_share(64, r, 8) for r in (0, 3, 7)] == [(0, 8), (24, 8), (56, 8)]
+    assert sharding.batch_share(64, 1, 2) == (32, 32) and sharding.batch_share(64, 0, 1) == (0, 64)
+    with pytest.raises(ValueError):
+        sharding.batch_share(64, 0, 3)
 
 
 def _grad_worker(rank, world, port, ret):

@@ -6,7 +6,7 @@ from collections import defaultdict
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "pmc_final")
 tag = sys.argv[1]
-names = {"render_kernel": "march", "pre_march_kernel": "pre", "ray_setup_kernel": "setup"}
+names = {"march_kernel": "march", "render_kernel": "march", "pre_march_kernel": "pre", "ray_setup_kernel": "setup"}
 lines = ["# rocprofv3 --pmc (one group per run, with --kernel-trace only) on: python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-p24 --spinup-ms 0",
          "# workload C1: 128x128 rays, B=1, Nc 48 + Nf 64, P=23, f16x3; mean over the launches of each kernel",
          "# march = enarf::render_kernel<3,1>, pre = enarf::pre_march_kernel (re-layout + prepare + ray set-up); SQ_* cycle counters are quad-cycles (x4 = cycles)",
@@ -35,4 +35,37 @@ if ("march", "FETCH_SIZE") in vals:
                "note": f"rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes (profiles/{tag}_pmc_summary.txt); FETCH_SIZE doubled "
                        "per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B); L2->fabric requests, Infinity-Cache hits included"},
               open(os.path.join(root, "profiles", "traffic.json"), "w"), indent=1)
+# ---- counter-backed utilisation of the march (read by bench.py as roofline.counters when the workload matches) ----------
+def kernel_avg_ns(stats_csv, key):
+    for r in csv.DictReader(open(stats_csv)):
+        if key in r.get("Name", ""):
+            return float(r["AverageNs"])
+    return None
+
+
+if st and ("march", "SQ_WAVE_CYCLES") in vals:
+    t_ns = kernel_avg_ns(st[-1], "march_kernel") or kernel_avg_ns(st[-1], "render_kernel")
+    t = t_ns * 1e-9
+    g = lambda c: vals.get(("march", c), 0.0)
+    # persistent waves live for the whole launch: their mean lifetime in shader cycles is the launch's cycle count
+    cycles = 4.0 * g("SQ_WAVE_CYCLES") / max(g("SQ_WAVES"), 1.0)
+    hbm_bytes = (2 * g("FETCH_SIZE") + g("WRITE_SIZE")) * 1024
+    src = f"profiles/{tag}_pmc_summary.txt"
+    fr = {
+        "ta_busy": {"value": g("TA_TA_BUSY_sum") / (256 * cycles), "formula": "TA_TA_BUSY_sum / (256 CUs x cycles)", "source": src},
+        "valu_busy": {"value": 4 * g("SQ_ACTIVE_INST_VALU") / (1024 * cycles), "formula": "4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x cycles)", "source": src},
+        "mfma_busy": {"value": g("SQ_VALU_MFMA_BUSY_CYCLES") / (1024 * cycles), "formula": "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x cycles)", "source": src},
+        "lds_busy": {"value": 4 * g("SQ_ACTIVE_INST_LDS") / (1024 * cycles), "formula": "4 x SQ_ACTIVE_INST_LDS / (1024 SIMDs x cycles)", "source": src},
+        "l2_read": {"value": g("TCP_TCC_READ_REQ_sum") * 64 / t / 34.5e12, "formula": "TCP_TCC_READ_REQ_sum x 64 B / t / 34.5 TB/s", "source": src},
+        "hbm": {"value": hbm_bytes / t / 8e12, "formula": "(2 x FETCH_SIZE + WRITE_SIZE) KB / t / 8 TB/s (FETCH_SIZE doubled on gfx950, MI355X_MICROARCH.md)", "source": src},
+        "wave_parked": {"value": g("SQ_WAIT_ANY") / max(g("SQ_WAVE_CYCLES"), 1.0), "formula": "SQ_WAIT_ANY / SQ_WAVE_CYCLES (s_waitcnt, barriers, sleep)", "source": src},
+        "wave_issue_stalled": {"value": g("SQ_WAIT_INST_ANY") / max(g("SQ_WAVE_CYCLES"), 1.0), "formula": "SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES", "source": src},
+        "l1_hit": {"value": 1.0 - g("TCP_TCC_READ_REQ_sum") / max(g("TCP_TOTAL_CACHE_ACCESSES_sum"), 1.0), "formula": "1 - TCP_TCC_READ_REQ_sum / TCP_TOTAL_CACHE_ACCESSES_sum", "source": src},
+        "l2_hit": {"value": g("TCC_HIT_sum") / max(g("TCC_HIT_sum") + g("TCC_MISS_sum"), 1.0), "formula": "TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum)", "source": src},
+    }
+    limiter = max(("ta_busy", "valu_busy", "mfma_busy", "l2_read", "hbm"), key=lambda k: fr[k]["value"])
+    json.dump({"workload_key": os.environ.get("WORKLOAD_KEY", "C1:128:1:48:64:23:f16x3:0:0.0"), "kernel_ms": t_ns * 1e-6, "cycles_per_launch": cycles,
+               "clock_ghz_under_profiler": cycles / t / 1e9, "hbm_bytes_per_launch": int(hbm_bytes), "limiter": limiter, "fractions": fr,
+               "kernel_stats": f"profiles/{tag}_kernel_stats.csv"},
+              open(os.path.join(root, "profiles", "r02_roofline.json"), "w"), indent=1)
 print("\n".join(lines[4:]))
