@@ -27,6 +27,7 @@ def library_info() -> dict:
     """What is (or will be) loaded: path and whether it is a variant build - bench.py prints this."""
     return {"path": LIB_PATH, "variant": _variant}
 
+ABI_VERSION = 2
 MAX_JOINTS = 32
 MAX_PARTS = 32
 FEAT_DIM = 32
@@ -60,6 +61,7 @@ class QueryArgs(C.Structure):
         ("mlp_pack", _f32p), ("density", _f32p), ("color", _f32p), ("valid_bits", _f32p),
         ("dbg_canonical", _f32p), ("dbg_weight", _f32p),
         ("grid_D", C.c_int), ("grid_center", C.c_float * 3), ("grid_scale", C.c_float),
+        ("clamp_mask", C.c_int), ("uniform_part_weight", C.c_int),
     ]
 
 
@@ -76,7 +78,7 @@ class RenderArgs(C.Structure):
         ("dbg_depth_min", _f32p), ("dbg_depth_max", _f32p), ("dbg_ray_valid", _f32p),
         ("dbg_coarse_density", _f32p), ("dbg_fine_density", _f32p), ("dbg_fine_color", _f32p),
         ("dbg_fine_valid", _f32p), ("dbg_bins", _f32p), ("counters", _f32p), ("workspace", _f32p),
-        ("ws_epoch", C.c_int),
+        ("clamp_mask", C.c_int), ("uniform_part_weight", C.c_int), ("ws_epoch", C.c_int),
     ]
 
 
@@ -93,6 +95,7 @@ class RenderBwdArgs(C.Structure):
         ("grad_mask_planes", _f32p), ("grad_mask_batch_stride", C.c_longlong),
         ("rows_x", _f32p), ("rows_h1", _f32p), ("rows_h2", _f32p), ("rows_dz1", _f32p), ("rows_dz2", _f32p),
         ("rows_dz3", _f32p), ("rows_per_image", C.c_longlong), ("row_blocks", _f32p), ("workspace", _f32p),
+        ("clamp_mask", C.c_int), ("uniform_part_weight", C.c_int),
     ]
 
 
@@ -107,6 +110,7 @@ class QueryBwdArgs(C.Structure):
         ("grad_mask_planes", _f32p), ("grad_mask_batch_stride", C.c_longlong),
         ("rows_x", _f32p), ("rows_h1", _f32p), ("rows_h2", _f32p), ("rows_dz1", _f32p), ("rows_dz2", _f32p),
         ("rows_dz3", _f32p), ("rows_per_image", C.c_longlong), ("row_blocks", _f32p),
+        ("clamp_mask", C.c_int), ("uniform_part_weight", C.c_int),
     ]
 
 
@@ -192,8 +196,8 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)      # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.enarf_abi_version() != 1:
-        raise EnarfHipError(f"libenarf_hip.so ABI {lib.enarf_abi_version()} != 1")
+    if lib.enarf_abi_version() != ABI_VERSION:
+        raise EnarfHipError(f"libenarf_hip.so ABI {lib.enarf_abi_version()} != {ABI_VERSION}")
     _lib = lib
     return lib
 

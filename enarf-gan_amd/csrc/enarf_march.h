@@ -53,8 +53,9 @@ __device__ __forceinline__ void stage_common(float *lds, QueryCtx &S, float *&sc
 __device__ __forceinline__ float density_head(float sigma_act, uint32_t bits, float wmax, int mult_w, int P) {
     float d = fmaxf(sigma_act, 0.0f);
     if (mult_w) {
-        // max over ALL parts of the weight tensor; invalid parts sit at sigmoid(0)^3 = 0.125
-        const float wm = (__popc(bits) < P) ? fmaxf(wmax, 0.125f) : wmax;
+        // max over ALL parts of the weight tensor; invalid parts sit at sigmoid(0)^3 = 0.125. mult_w == 2:
+        // no_selector, every entry of the weight tensor is 1 / P (models/narf.py:133-134)
+        const float wm = (mult_w == 2) ? 1.0f / (float)P : (__popc(bits) < P) ? fmaxf(wmax, 0.125f) : wmax;
         d = d * (10.0f * wm);
     } else {
         d = d * 10.0f;

@@ -72,6 +72,8 @@ struct QueryCtx {
     const float *mask;       // global: this image's part-probability planes [P*3][H][W]
     int H, W, P;
     int mult_w;              // multiply_density_with_triplane_wieght
+    int clamp_mask;          // nerf_params.clamp_mask (sampling.py:46-47)
+    float uniform_w;         // > 0: nerf_params.no_selector, every part weighs this (1 / P); 0: part-probability planes
 #if ENARF_DIAG_TAPCHECK
     unsigned long long *diag;   // counters[5] violations, [6] first: rid | k << 32 | lane << 40 | kind << 48, [7] qx, qy bits
     unsigned diag_rid;
@@ -673,8 +675,10 @@ __device__ __forceinline__ void query_tile(const QueryCtx &S, const int *cand_li
             macc += m01 * t.w01;
             macc += m10 * t.w10;
             macc += m11 * t.w11;
+            if (S.clamp_mask) macc = fminf(fmaxf(macc, -2.0f), 5.0f);
             const float sg = sigmoidf_(macc);
-            const float w = (quad_bcast_f<0>(sg) * quad_bcast_f<1>(sg)) * quad_bcast_f<2>(sg);
+            const float wp = (quad_bcast_f<0>(sg) * quad_bcast_f<1>(sg)) * quad_bcast_f<2>(sg);
+            const float w = (S.uniform_w > 0.0f) ? S.uniform_w : wp;
             float acc[8], s1[8], s2[8];
             TMR2(S, 2);
             TMR2_WAIT(S, 3, 0x0F78);     // vmcnt(8)

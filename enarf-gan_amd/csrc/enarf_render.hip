@@ -186,7 +186,8 @@ __global__ __launch_bounds__(256) void query_kernel(const enarf_query_args a, in
                        a.parts + (size_t)b * a.P * kPartStride, a.canonical_pose, a.P, tid, 256);
     S.feat = a.feat_cl + (size_t)b * a.feat_batch_stride;
     S.mask = a.mask_planes + (size_t)b * a.mask_batch_stride;
-    S.H = a.H; S.W = a.W; S.P = a.P; S.mult_w = a.multiply_density_with_weight;
+    S.H = a.H; S.W = a.W; S.P = a.P; S.mult_w = a.multiply_density_with_weight ? (a.uniform_part_weight ? 2 : 1) : 0;
+    S.clamp_mask = a.clamp_mask; S.uniform_w = a.uniform_part_weight ? 1.0f / (float)a.P : 0.0f;
 #if ENARF_DIAG_TAPCHECK
     S.diag = nullptr; S.diag_rid = 0;
 #endif
@@ -551,7 +552,8 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
                        a.parts + (size_t)b * P * kPartStride, a.canonical_pose, P, tid, 256);
     S.feat = a.feat_cl + (size_t)b * a.feat_batch_stride;
     S.mask = a.mask_planes + (size_t)b * a.mask_batch_stride;
-    S.H = a.H; S.W = a.W; S.P = P; S.mult_w = a.multiply_density_with_weight;
+    S.H = a.H; S.W = a.W; S.P = P; S.mult_w = a.multiply_density_with_weight ? (a.uniform_part_weight ? 2 : 1) : 0;
+    S.clamp_mask = a.clamp_mask; S.uniform_w = a.uniform_part_weight ? 1.0f / (float)P : 0.0f;
     float *l_btab = scratch + SC_BTAB;
     int *l_cand = reinterpret_cast<int *>(scratch + SC_CAND) + wave * 32;
     float *l_ch = scratch + SC_CH, *l_cwmax = scratch + SC_CWMAX, *l_fh = scratch + SC_FH, *l_fwmax = scratch + SC_FWMAX;

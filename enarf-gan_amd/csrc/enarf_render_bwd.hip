@@ -172,9 +172,11 @@ __device__ __forceinline__ void bwd_gather_tile(const QueryCtx &S, const BwdTile
                 acc += mp[t.o01] * t.w01;
                 acc += mp[t.o10] * t.w10;
                 acc += mp[t.o11] * t.w11;
+                if (S.clamp_mask) acc = fminf(fmaxf(acc, -2.0f), 5.0f);
                 sg = sigmoidf_(acc);
             }
-            const float wk = (quad_bcast_f<0>(sg) * quad_bcast_f<1>(sg)) * quad_bcast_f<2>(sg);
+            const float wp = (quad_bcast_f<0>(sg) * quad_bcast_f<1>(sg)) * quad_bcast_f<2>(sg);
+            const float wk = (S.uniform_w > 0.0f) ? S.uniform_w : wp;
             const Taps t0 = quad_bcast_taps<0>(t), t1 = quad_bcast_taps<1>(t), t2 = quad_bcast_taps<2>(t);
             if (act) {
                 float s0[8], s1[8], s2[8];
@@ -246,9 +248,11 @@ __device__ __forceinline__ void bwd_backward_tile(const QueryCtx &S, const BwdTi
             acc += mp[t.o01] * t.w01;
             acc += mp[t.o10] * t.w10;
             acc += mp[t.o11] * t.w11;
+            if (S.clamp_mask) acc = fminf(fmaxf(acc, -2.0f), 5.0f);     // gradient straight through (sampling.py:46-47)
             sg = sigmoidf_(acc);
         }
-        const float wk = (quad_bcast_f<0>(sg) * quad_bcast_f<1>(sg)) * quad_bcast_f<2>(sg);
+        const float wp = (quad_bcast_f<0>(sg) * quad_bcast_f<1>(sg)) * quad_bcast_f<2>(sg);
+        const float wk = (S.uniform_w > 0.0f) ? S.uniform_w : wp;
         const Taps t0 = quad_bcast_taps<0>(t), t1 = quad_bcast_taps<1>(t), t2 = quad_bcast_taps<2>(t);
         float dot = 0.0f;
         if (act) {
@@ -263,8 +267,8 @@ __device__ __forceinline__ void bwd_backward_tile(const QueryCtx &S, const BwdTi
         dot += quad_perm_f<0xB1>(dot);
         dot += quad_perm_f<0x4E>(dot);                                  // d loss / d w_k, quad-uniform
         {   // w = s0 s1 s2, s = sigmoid(m): dw/dm_g = w (1 - s_g); lane g adds into the four taps of its plane
-            const bool mon = act && g4 < 3 && !(ENARF_BWD_ABLATE & 2);
-            const float gm = mon ? dot * wk * (1.0f - sg) : 0.0f;
+            const bool mon = act && g4 < 3 && !(ENARF_BWD_ABLATE & 2) && !(S.uniform_w > 0.0f);     // uniform weights: no plane gradient
+            const float gm = mon ? dot * wp * (1.0f - sg) : 0.0f;
             const int pbase = (3 * k + g4) * (int)T.mplane;
             mask_tap_add(T.gmask, mon && t.w00 != 0.0f, pbase + t.o00, t.w00 * gm, lane);
             mask_tap_add(T.gmask, mon && t.w01 != 0.0f, pbase + t.o01, t.w01 * gm, lane);
@@ -314,6 +318,7 @@ __global__ __launch_bounds__(256, kBwdWavesPerSimd) void render_bwd_kernel(const
     QueryCtx S;
     S.mlp = l_w; S.mlp_h = nullptr; S.bias = l_bias; S.parts = l_parts; S.canon = l_canon;
     S.H = a.H; S.W = a.W; S.P = P; S.mult_w = 0;
+    S.clamp_mask = a.clamp_mask; S.uniform_w = a.uniform_part_weight ? 1.0f / (float)P : 0.0f;
     int *l_cand = reinterpret_cast<int *>(scratch + SB_CAND) + wave * 32;
     float *l_fh = scratch + SB_FH, *l_dz3 = scratch + SB_DZ3;
     float *ttile = scratch + kBwdScratchFloats + wave * kTTile;     // this wave's atomic-transpose tile
@@ -442,6 +447,7 @@ __global__ __launch_bounds__(256, kBwdWavesPerSimd) void query_bwd_kernel(const 
     QueryCtx S;
     S.mlp = l_w; S.mlp_h = nullptr; S.bias = l_bias; S.parts = l_parts; S.canon = l_canon;
     S.H = a.H; S.W = a.W; S.P = P; S.mult_w = 0;
+    S.clamp_mask = a.clamp_mask; S.uniform_w = a.uniform_part_weight ? 1.0f / (float)P : 0.0f;
     S.feat = a.feat_cl + (size_t)b * a.feat_batch_stride;
     S.mask = a.mask_planes + (size_t)b * a.mask_batch_stride;
     int *l_cand = reinterpret_cast<int *>(scratch + SB_CAND);

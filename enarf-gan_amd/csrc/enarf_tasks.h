@@ -66,6 +66,7 @@ constexpr int SH_PENDING = 3;             // slots that hold a popped ray of ano
 constexpr int SH_CTXB = 4;                // image whose context is staged
 constexpr int SH_SWITCHING = 5;           // a context switch is in progress
 constexpr int SH_ERROR = 6;               // watchdog: a wave found no work for kIdleLimit polls although chains are alive
+constexpr int SH_FIRST = 7;               // the workgroup's first ray (decides which image is staged at start)
 constexpr int SH_QCOUNTS = 8;             // list lengths [kQueues * kClasses]
 constexpr int SH_BTAB = SH_QCOUNTS + kQueues * kClasses;       // Nc + 1 bin edges (<= 129 floats)
 constexpr int SH_PENDFLAG = SH_BTAB + 132;                     // per slot: 1 = holds a pending ray
@@ -92,8 +93,10 @@ __device__ __forceinline__ unsigned wave_lds_cas(unsigned *p, unsigned expect, u
     if (lane == 0) r = atomicCAS(p, expect, desired);
     return (unsigned)__builtin_amdgcn_readfirstlane((int)r);
 }
-__device__ __forceinline__ void lds_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
-__device__ __forceinline__ void lds_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+// everything the waves of the workgroup hand to each other lives in LDS: fences of the LOCAL address space only, so that a
+// wave's outstanding global stores (a ray's outputs) are not waited for before it publishes the next piece of work
+__device__ __forceinline__ void lds_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); }
+__device__ __forceinline__ void lds_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); }
 
 // The ray queues of enarf_march.h, popped by ANY wave of the workgroup at any time (the round-1 RayQueue had one popper
 // at a time): the cursor is one packed word that only ever moves past lists somebody has seen exhausted.
@@ -189,7 +192,7 @@ __device__ __forceinline__ void draw_sorted_uniforms(RenderArgsK a, uint32_t rid
 // S2 of one ray (ONE wave, element e = 64 s + lane): coarse weights (rendering.py:180-184), smoothing (:187-190), the
 // importance samples (:192-197) and the early-termination flags of the fine tiles; everything from / to the slot
 template <int SPL>
-__device__ __noinline__ void ray_sample_stage(RenderArgsK a, const MarchCtx &M, unsigned *sw, int mult_w, int lane) {
+__device__ __noinline__ void ray_sample_stage(RenderArgsK a, const float *l_btab, unsigned *sw, int mult_w, int lane) {
     const int P = a->P, Nc = a->Nc, Nf = a->Nf, n = a->n;
     const RayRec rec = *reinterpret_cast<const RayRec *>(sw + SL_REC);
     const uint32_t rid = sw[SL_RID];
@@ -199,7 +202,6 @@ __device__ __noinline__ void ray_sample_stage(RenderArgsK a, const MarchCtx &M, 
     const uint32_t *l_cbits = sw + SL_CBITS;
     float *l_bins = reinterpret_cast<float *>(sw + SL_BINS);
     int *l_skip = reinterpret_cast<int *>(sw + SL_SKIP);
-    const float *l_btab = M.btab;
     float bin[SPL];
     float dd[SPL], cs[SPL], T[SPL], wgt[SPL], ws[SPL], wl[SPL], wr[SPL];
 #pragma unroll
@@ -471,8 +473,8 @@ __device__ __forceinline__ void release_token(RenderArgsK a, const MarchCtx &M, 
 
 // next ray for slot s (the caller holds the slot's token): publish it, park it (other image) or end the chain
 template <int MODE>
-__device__ __noinline__ void refill_slot(RenderArgsK a, const MarchCtx &M, TaskQueue &tq, float *lds, int s, int lane,
-                                            MarchCounters &C) {
+__device__ __noinline__ unsigned refill_slot(RenderArgsK a, const MarchCtx M, TaskQueue tq, float *lds, int s, int lane) {
+    unsigned popped = 0u;                            // rays this call took off the queues (for the launch's counters)
     unsigned *sw = M.slots + s * kSlotWords;
     RayRec rec;
     int rid;
@@ -491,12 +493,12 @@ __device__ __noinline__ void refill_slot(RenderArgsK a, const MarchCtx &M, TaskQ
         rid = -1;
     } else {
         rid = tq.pop(rec, lane);
-        if (rid >= 0) C.rays += 1;
+        if (rid >= 0) popped = 1u;
     }
     if (rid < 0) {                                   // queues drained: this slot's chain ends
         if (lane == 0) atomicAdd(&M.sh[SH_DEAD], 1u);
         release_token<MODE>(a, M, lds, lane);
-        return;
+        return popped;
     }
     if (lane == 0) { sw[SL_RID] = (unsigned)rid; *reinterpret_cast<RayRec *>(sw + SL_REC) = rec; }
     const unsigned b = (unsigned)rid / (uint32_t)a->n;
@@ -507,18 +509,19 @@ __device__ __noinline__ void refill_slot(RenderArgsK a, const MarchCtx &M, TaskQ
         if (lane == 0) { M.sh[SH_PENDFLAG + s] = 1u; atomicAdd(&M.sh[SH_PENDING], 1u); }
         release_token<MODE>(a, M, lds, lane);
     }
+    return popped;
 }
 
 // pop the slot's NEXT ray while its current one is in the fine pass (called by the wave that ran S2, after it has published
 // the fine tiles): the queue's dependent chain - atomic, list entry, 32-byte record - then costs the slot nothing
-__device__ __noinline__ void prefetch_next_ray(const MarchCtx &M, TaskQueue &tq, unsigned *sw, int lane, MarchCounters &C) {
-    if (wave_lds_cas(sw + SL_NEXT_STATE, 0u, 3u, lane) != 0u) return;       // one is held or in flight already
+__device__ __noinline__ unsigned prefetch_next_ray(TaskQueue tq, unsigned *sw, int lane) {
+    if (wave_lds_cas(sw + SL_NEXT_STATE, 0u, 3u, lane) != 0u) return 0u;    // one is held or in flight already
     RayRec rec;
     const int rid = tq.pop(rec, lane);
     if (lane == 0 && rid >= 0) { sw[SL_NEXT_RID] = (unsigned)rid; *reinterpret_cast<RayRec *>(sw + SL_NEXT_REC) = rec; }
     lds_release();
     if (lane == 0) __hip_atomic_store(sw + SL_NEXT_STATE, rid >= 0 ? 1u : 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if (rid >= 0) C.rays += 1;
+    return rid >= 0 ? 1u : 0u;
 }
 
 // =================================================================================================================================
@@ -539,7 +542,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void march_kernel(const enarf_rend
         S.mlp = l_mlp; S.mlp_h = reinterpret_cast<const short *>(l_mlp); S.bias = l_bias; S.parts = l_parts; S.canon = l_canon;
     }
     S.feat = a.feat_cl; S.mask = a.mask_planes;
-    S.H = a.H; S.W = a.W; S.P = P; S.mult_w = a.multiply_density_with_weight;
+    S.H = a.H; S.W = a.W; S.P = P; S.mult_w = a.multiply_density_with_weight ? (a.uniform_part_weight ? 2 : 1) : 0;
+    S.clamp_mask = a.clamp_mask; S.uniform_w = a.uniform_part_weight ? 1.0f / (float)P : 0.0f;
 #if ENARF_DIAG_TAPCHECK
     S.diag = nullptr; S.diag_rid = 0;
 #endif
@@ -566,13 +570,37 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void march_kernel(const enarf_rend
 
     MarchCounters C{0u, 0u, 0u, 0u, 0u};
     const RenderArgsK ak = kernel_render_args();
-#if ENARF_TIMERS == 5   // diagnostic build: per-wave cycles in 0 tiles, 1 S2, 2 S4, 3 pop / publish / stage, 4 idle, 5 scan + claim
-    unsigned long long tm[6] = {0, 0, 0, 0, 0, 0}, t_last = __builtin_amdgcn_s_memtime();
+    // the first ray decides which image's context the WHOLE workgroup stages (one wave alone takes ~40 us for the 29 KB)
+    if (wave == 0) {
+        RayRec rec;
+        const int rid = tq.pop(rec, lane);
+        if (lane == 0) {
+            M.sh[SH_FIRST] = (unsigned)rid;
+            if (rid >= 0) { M.slots[SL_RID] = (unsigned)rid; *reinterpret_cast<RayRec *>(M.slots + SL_REC) = rec; }
+        }
+        if (rid >= 0) C.rays += 1;
+    }
+    __syncthreads();
+    const int first = (int)M.sh[SH_FIRST];
+    if (first < 0) return;                         // uniform: every queue was drained before this workgroup got a ray
+    {
+        const int b0 = (int)((unsigned)first / (uint32_t)a.n);
+        QueryCtx tmp;
+        float *unused;
+        stage_common<MODE>(lds, tmp, unused, reinterpret_cast<const char *>(a.mlp_pack) + (size_t)b0 * kPackBytes,
+                           a.parts + (size_t)b0 * P * kPartStride, a.canonical_pose, P, tid, NW * 64);
+        if (tid == 0) M.sh[SH_CTXB] = (unsigned)b0;
+    }
+    __syncthreads();
+    if (wave == 0) publish_ray(M, M.slots, lane);   // slot 0 holds the first ray (and one of the initial tokens)
+#if ENARF_TIMERS == 5   // diagnostic build: per-wave cycles in 0 tiles, 1 S2, 2 S4, 3 refill after S4 (+ start-up), 4 idle, 5 scan + claim, 6 pop-ahead
+    unsigned long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last = __builtin_amdgcn_s_memtime();
 #define TK(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tm[k] += now_ - t_last; t_last = now_; } while (0)
 #else
 #define TK(k) do { } while (0)
 #endif
-    for (int s = wave; s < nslots; s += NW) refill_slot<MODE>(ak, M, tq, lds, s, lane, C);      // the first pops park; the last one stages
+    for (int s = wave; s < nslots; s += NW)
+        if (s != 0) C.rays += refill_slot<MODE>(ak, M, tq, lds, s, lane);
     TK(3);
 
     volatile unsigned *vsl = M.slots;
@@ -603,7 +631,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void march_kernel(const enarf_rend
                 lds_acquire();
                 if (!fine) {
                     __builtin_amdgcn_s_setprio(3);   // fine tiles of this ray cannot start before this is done
-                    ray_sample_stage<SPL>(ak, M, sw, S.mult_w, lane);
+                    ray_sample_stage<SPL>(ak, M.btab, sw, S.mult_w, lane);
                     __builtin_amdgcn_s_setprio(0);
                     if (lane == 0) sw[SL_DONE] = 0u;
                     lds_release();
@@ -611,12 +639,16 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void march_kernel(const enarf_rend
                         __hip_atomic_store(&sw[SL_CTL], pack_ctl(ctl_gen(old), ST_FINE, (unsigned)M.nft, 0u), __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_WORKGROUP);
                     TK(1);
-                    prefetch_next_ray(M, tq, sw, lane, C);
-                    TK(3);
+                    __builtin_amdgcn_s_setprio(1);
+                    C.rays += prefetch_next_ray(tq, sw, lane);
+                    __builtin_amdgcn_s_setprio(0);
+                    TK(6);
                 } else {
+                    __builtin_amdgcn_s_setprio(3);   // the slot is empty until this chain has published its next ray
                     ray_composite_stage<SPL>(ak, sw, S.mult_w, lane);
                     TK(2);
-                    refill_slot<MODE>(ak, M, tq, lds, s, lane, C);       // the slot keeps its token across the pop
+                    C.rays += refill_slot<MODE>(ak, M, tq, lds, s, lane);       // the slot keeps its token across the pop
+                    __builtin_amdgcn_s_setprio(0);
                     TK(3);
                 }
             }
@@ -636,7 +668,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void march_kernel(const enarf_rend
     }
 #if ENARF_TIMERS == 5
     if (a.counters && lane == 0)
-        for (int k = 0; k < 6; ++k) atomicAdd(&a.counters[k], tm[k]);
+        for (int k = 0; k < 8; ++k) atomicAdd(&a.counters[k], tm[k]);
     return;
 #endif
     if (a.counters && lane == 0) {

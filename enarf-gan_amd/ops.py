@@ -334,7 +334,8 @@ def _plane_strides(tri_nchw: torch.Tensor, feat_cl: torch.Tensor, B: int):
 def query_fwd(points: Optional[torch.Tensor], parts: torch.Tensor, canonical_pose: torch.Tensor, tri_nchw: torch.Tensor,
               feat_cl: torch.Tensor, mlp_pack: torch.Tensor, mlp_mode: str = "f32",
               multiply_density_with_weight: bool = False, need_color: bool = True, need_valid: bool = False,
-              debug: bool = False, grid: Optional[Tuple[int, Sequence[float], float]] = None):
+              debug: bool = False, grid: Optional[Tuple[int, Sequence[float], float]] = None, clamp_mask: bool = False,
+              uniform_part_weight: bool = False):
     """points (B,3,N) -> density (B,1,N), color (B,3,N) [, valid_bits (B,N) int32 [, canonical, weight]].
 
     grid = (D, centre (3,), scale) with points = None: the D^3 lattice of create_mesh, generated in the kernel."""
@@ -369,6 +370,7 @@ def query_fwd(points: Optional[torch.Tensor], parts: torch.Tensor, canonical_pos
     a = _lib.QueryArgs()
     a.B, a.N, a.P, a.H, a.W = B, N, P, H, W
     a.mlp_mode, a.multiply_density_with_weight = MLP_MODE[mlp_mode], int(multiply_density_with_weight)
+    a.clamp_mask, a.uniform_part_weight = int(bool(clamp_mask)), int(bool(uniform_part_weight))
     a.points, a.parts, a.canonical_pose = (None if grid is not None else _p(pts)), _p(parts), _p(_dev_f32(canonical_pose, "canonical_pose"))
     if grid is not None:
         a.grid_D, a.grid_scale = int(grid[0]), float(grid[2])
@@ -440,13 +442,14 @@ def render_fwd(image_coord: torch.Tensor, inv_intrinsics: torch.Tensor, parts: t
                Nc: int, Nf: int, render_scale: float = 1.0, bins: Optional[torch.Tensor] = None, seed: int = 0,
                mlp_mode: str = "f32", multiply_density_with_weight: bool = False,
                drop_invalid_rays: Optional[bool] = None, want_fine: bool = True, debug: bool = False,
-               count: bool = False, early_stop_eps: float = 0.0, return_bins: bool = False) -> RenderOutputs:
+               count: bool = False, early_stop_eps: float = 0.0, return_bins: bool = False, clamp_mask: bool = False,
+               uniform_part_weight: bool = False) -> RenderOutputs:
     """The fused ray march. image_coord (B,1,3,n) or (B,3,n); returns color (B,3,n), mask (B,n), disparity (B,n),
     fine_weights (B,1,n,Nf-1), fine_depth (B,1,n,Nf) and, with debug=True, the parity taps."""
     lib = _lib.load()
     a, o, _keep = _render_args(image_coord, inv_intrinsics, parts, canonical_pose, tri_nchw, feat_cl, mlp_pack, Nc, Nf,
                                render_scale, bins, seed, mlp_mode, multiply_density_with_weight, drop_invalid_rays,
-                               want_fine, debug, count, early_stop_eps, return_bins)
+                               want_fine, debug, count, early_stop_eps, return_bins, clamp_mask, uniform_part_weight)
     with _Epoch(o.color.device) as k:
         a.ws_epoch = k
         _lib.check(lib.enarf_render_fwd(C.byref(a), _stream(o.color.device)), "enarf_render_fwd")
@@ -455,7 +458,7 @@ def render_fwd(image_coord: torch.Tensor, inv_intrinsics: torch.Tensor, parts: t
 
 def _render_args(image_coord, inv_intrinsics, parts, canonical_pose, tri_nchw, feat_cl, mlp_pack, Nc, Nf, render_scale,
                  bins, seed, mlp_mode, multiply_density_with_weight, drop_invalid_rays, want_fine, debug, count,
-                 early_stop_eps, return_bins):
+                 early_stop_eps, return_bins, clamp_mask=False, uniform_part_weight=False):
     """enarf_render_args with freshly allocated outputs + the tensors its pointers borrow."""
     coord = _dev_f32(image_coord, "image_coord")
     B, n = coord.shape[0], coord.shape[-1]
@@ -480,6 +483,7 @@ def _render_args(image_coord, inv_intrinsics, parts, canonical_pose, tri_nchw, f
     a.mlp_mode, a.multiply_density_with_weight = MLP_MODE[mlp_mode], int(multiply_density_with_weight)
     a.drop_invalid_rays = int(B == 1 if drop_invalid_rays is None else drop_invalid_rays)
     a.render_scale, a.early_stop_eps = float(render_scale), float(early_stop_eps)
+    a.clamp_mask, a.uniform_part_weight = int(bool(clamp_mask)), int(bool(uniform_part_weight))
     a.image_coord, a.inv_intrinsics, a.parts = _p(coord), _p(Ki), _p(parts)
     cpose = _dev_f32(canonical_pose, "canonical_pose")
     a.canonical_pose = _p(cpose)
@@ -527,7 +531,7 @@ class RenderStep:
                  coordinate_scale, image_coord, inv_intrinsics, canonical_pose, tri_nchw, feat_cl, Nc, Nf,
                  parts_out=None, pack_out=None, relayout=True, render_scale=1.0, bins=None, seed=0, mlp_mode="f32",
                  multiply_density_with_weight=False, drop_invalid_rays=None, want_fine=True, debug=False, count=False,
-                 early_stop_eps=0.0, return_bins=False):
+                 early_stop_eps=0.0, return_bins=False, clamp_mask=False, uniform_part_weight=False):
         self.lib = _lib.load()
         self.pa, k1, self.parts, self.pack = _prepare_args(pose_to_camera, bone_length, canonical_bone_length, z_rend,
                                                            mlp, parents, origin_location, coordinate_scale, parts_out,
@@ -535,7 +539,7 @@ class RenderStep:
         self.ra, self.out, k2 = _render_args(image_coord, inv_intrinsics, self.parts, canonical_pose, tri_nchw, feat_cl,
                                              self.pack, Nc, Nf, render_scale, bins, seed, mlp_mode,
                                              multiply_density_with_weight, drop_invalid_rays, want_fine, debug, count,
-                                             early_stop_eps, return_bins)
+                                             early_stop_eps, return_bins, clamp_mask, uniform_part_weight)
         self.tri = _dev_f32(tri_nchw, "tri_plane")
         self.feat_cl, self.relayout = feat_cl, relayout
         if feat_cl.shape[0] != self.tri.shape[0]:
@@ -575,7 +579,7 @@ def render_step_fwd(*args, **kw) -> RenderOutputs:
 @_on_tensor_device
 def render_bwd(image_coord, inv_intrinsics, parts, canonical_pose, tri_nchw, feat_cl, mlp_pack, Nf, bins,
                g_color, g_mask, g_disparity=None, render_scale: float = 1.0, drop_invalid_rays: Optional[bool] = None,
-               feat_grad_channel_last: bool = False):
+               feat_grad_channel_last: bool = False, clamp_mask: bool = False, uniform_part_weight: bool = False):
     """Backward of render_fwd w.r.t. the tri-plane and the per-image demodulated MLP weights / biases.
 
     Returns (grad_tri (same batch as tri_nchw: 1 for a shared tri-plane), dW [3 x (B,out,in)], db [3 x (out,)]).
@@ -602,6 +606,7 @@ def render_bwd(image_coord, inv_intrinsics, parts, canonical_pose, tri_nchw, fea
     a.B, a.n, a.P, a.Nf, a.H, a.W = B, n, P, Nf, H, W
     a.drop_invalid_rays = int(B == 1 if drop_invalid_rays is None else drop_invalid_rays)
     a.render_scale = float(render_scale)
+    a.clamp_mask, a.uniform_part_weight = int(bool(clamp_mask)), int(bool(uniform_part_weight))
     a.image_coord, a.inv_intrinsics, a.parts = _p(coord), _p(Ki), _p(parts)
     a.canonical_pose = _p(_dev_f32(canonical_pose, "canonical_pose"))
     a.feat_cl, a.feat_batch_stride = _p(feat_cl), fstride
@@ -654,7 +659,8 @@ def _weight_grad(bufs, blocks, B: int, rows: int, dev: torch.device):
 
 
 @_on_tensor_device
-def query_bwd(points, parts, canonical_pose, tri_nchw, feat_cl, mlp_pack, g_density, g_color):
+def query_bwd(points, parts, canonical_pose, tri_nchw, feat_cl, mlp_pack, g_density, g_color, clamp_mask: bool = False,
+              uniform_part_weight: bool = False):
     """Backward of query_fwd w.r.t. the tri-plane and the per-image demodulated MLP weights / biases.
 
     points (B,3,N); g_density (B,1,N) or None; g_color (B,3,N) or None. Returns (grad_tri, dW [3 x (B,out,in)], db)."""
@@ -672,6 +678,7 @@ def query_bwd(points, parts, canonical_pose, tri_nchw, feat_cl, mlp_pack, g_dens
     gfeat = torch.zeros_like(feat_cl)
     a = _lib.QueryBwdArgs()
     a.B, a.P, a.H, a.W, a.N = B, P, H, W, N
+    a.clamp_mask, a.uniform_part_weight = int(bool(clamp_mask)), int(bool(uniform_part_weight))
     a.points, a.parts = _p(pts) if N else _p(torch.zeros(1, device=dev)), _p(parts)
     a.canonical_pose = _p(_dev_f32(canonical_pose, "canonical_pose"))
     a.feat_cl, a.feat_batch_stride = _p(feat_cl), fstride

@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define ENARF_ABI_VERSION 1
+#define ENARF_ABI_VERSION 2
 
 #define ENARF_ERR_ARG          (-1)   /* null pointer / non-positive size / bad enum */
 #define ENARF_ERR_UNSUPPORTED  (-2)   /* valid in the reference but not implemented here (message says what) */
@@ -177,6 +177,9 @@ typedef struct {
     int grid_D;
     float grid_center[3];
     float grid_scale;
+    /* part-probability variants of libraries/triplane/sampling.py:43-76 / models/narf.py:133-134 */
+    int clamp_mask;                       /* nerf_params.clamp_mask: plane samples clamped to [-2, 5] before the sigmoid */
+    int uniform_part_weight;              /* nerf_params.no_selector: every part weighs 1 / P (no part-probability planes read) */
 } enarf_query_args;
 
 int enarf_query_fwd(const enarf_query_args *args, enarf_stream_t stream);
@@ -229,6 +232,7 @@ typedef struct {
     void *workspace;                      /* device, >= enarf_render_workspace_bytes(B, n): two queue headers, per-ray
                                              records (depth range, candidate parts, direction) and the ray lists; one
                                              workspace must not be shared by launches that can overlap. */
+    int clamp_mask, uniform_part_weight;  /* as in enarf_query_args */
     int ws_epoch;                         /* 0: the call clears the queue headers itself (one extra fill launch on
                                              `stream`) - always safe. k > 0: the caller promises that the previous call
                                              that used this workspace had ws_epoch k - 1 (any of enarf_render_fwd /
@@ -281,6 +285,7 @@ typedef struct {
     long long rows_per_image;             /* >= enarf_render_bwd_rows_per_image(n, Nf) */
     unsigned int *row_blocks;             /* device (B,): 16-row blocks written per image (zeroed by the call) */
     void *workspace;                      /* as enarf_render_fwd */
+    int clamp_mask, uniform_part_weight;  /* as in enarf_query_args (clamp_mask: straight-through gradient, sampling.py:46-47) */
 } enarf_render_bwd_args;
 
 long long enarf_render_bwd_rows_per_image(int n, int Nf);
@@ -306,6 +311,7 @@ typedef struct {
     float *rows_x, *rows_h1, *rows_h2, *rows_dz1, *rows_dz2, *rows_dz3;   /* (B, rows_per_image, 32|64|64|64|64|4) */
     long long rows_per_image;             /* >= enarf_query_bwd_rows_per_image(N) */
     unsigned int *row_blocks;             /* device (B,): 16-row blocks written per image (zeroed by the call) */
+    int clamp_mask, uniform_part_weight;
 } enarf_query_bwd_args;
 long long enarf_query_bwd_rows_per_image(long long N);
 int enarf_query_bwd(const enarf_query_bwd_args *args, enarf_stream_t stream);

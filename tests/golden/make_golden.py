@@ -331,7 +331,7 @@ def run_sampling_case(name, seed):
     pos = torch.rand(B, 3, n, generator=g) * 2.4 - 1.2
     out_sum = sample_feature(planes, pos)                                   # B = 2: the F.grid_sample branch
     wplanes = torch.randn(B * P, 3, h, h, generator=g) * 3.0
-    ppos = torch.rand(B, P, 3, n, generator=g) * 2.2 - 1.1
+    ppos = torch.rand(B, P, 3, n, generator=g) * 1.998 - 0.999      # valid pairs are inside the cube (models/narf.py:200-201)
     valid = torch.rand(B, P, n, generator=g) > 0.4
     masked = ppos * valid[:, :, None] + 2 * ~valid[:, :, None]              # models/narf.py:237
     prob_prod = sample_triplane_part_prob(wplanes, masked, valid)

@@ -47,7 +47,7 @@ if os.environ.get("TIMERS") == "4":
              "3 S4 heads (tanh, density)", "4 S4 scan + weights", "5 S4 sums + stores", "6 barrier waits", "7 S1 + S3 (queries)"]
 if os.environ.get("TIMERS") == "5":
     names = ["0 query tiles (pass A, rounds, MLP)", "1 S2 weights + importance samples", "2 S4 compositing + outputs",
-             "3 pop / publish / image staging", "4 idle (no tile to claim)", "5 scan + claim", "-", "-"]
+             "3 refill after S4 (+ start-up)", "4 idle (no tile to claim)", "5 scan + claim", "6 pop-ahead of the next ray", "-"]
 if os.environ.get("TIMERS") == "3":
     c = out.counters.cpu().tolist()
     span = c[1] - c[0]
