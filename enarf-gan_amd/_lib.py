@@ -95,7 +95,7 @@ class RenderBwdArgs(C.Structure):
         ("grad_mask_planes", _f32p), ("grad_mask_batch_stride", C.c_longlong),
         ("rows_x", _f32p), ("rows_h1", _f32p), ("rows_h2", _f32p), ("rows_dz1", _f32p), ("rows_dz2", _f32p),
         ("rows_dz3", _f32p), ("rows_per_image", C.c_longlong), ("row_blocks", _f32p), ("workspace", _f32p),
-        ("clamp_mask", C.c_int), ("uniform_part_weight", C.c_int),
+        ("clamp_mask", C.c_int), ("uniform_part_weight", C.c_int), ("multiply_density_with_weight", C.c_int),
     ]
 
 
@@ -110,7 +110,7 @@ class QueryBwdArgs(C.Structure):
         ("grad_mask_planes", _f32p), ("grad_mask_batch_stride", C.c_longlong),
         ("rows_x", _f32p), ("rows_h1", _f32p), ("rows_h2", _f32p), ("rows_dz1", _f32p), ("rows_dz2", _f32p),
         ("rows_dz3", _f32p), ("rows_per_image", C.c_longlong), ("row_blocks", _f32p),
-        ("clamp_mask", C.c_int), ("uniform_part_weight", C.c_int),
+        ("clamp_mask", C.c_int), ("uniform_part_weight", C.c_int), ("multiply_density_with_weight", C.c_int),
     ]
 
 

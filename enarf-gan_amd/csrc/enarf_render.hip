@@ -1010,7 +1010,7 @@ int device_cus() {
 #define ENARF_TASK_WAVES 12
 #endif
 #ifndef ENARF_TASK_SLOTS
-#define ENARF_TASK_SLOTS 8
+#define ENARF_TASK_SLOTS 6
 #endif
 
 template <int MODE, int SPL>

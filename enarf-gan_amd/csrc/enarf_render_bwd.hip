@@ -23,12 +23,16 @@ namespace enarf {
 constexpr int kBwdWavesPerSimd = 2;
 
 // LDS scratch of the backward kernel (floats)
-constexpr int SB_CAND = 0;        // 4 waves x 32 ints
-constexpr int SB_FH = 128;        // head [4][64]
-constexpr int SB_FBITS = 384;     // bits [64]
-constexpr int SB_DZ3 = 448;       // dL/dz3 [4][64]
-constexpr int SB_QUEUE = 704;     // 2 ray ids
-constexpr int kBwdScratchFloats = 768;
+constexpr int kBwdMaxSamples = 128;
+constexpr int SB_CAND = 0;                                  // 4 waves x 32 ints
+constexpr int SB_FH = 128;                                  // head [4][128]
+constexpr int SB_FBITS = SB_FH + 4 * kBwdMaxSamples;        // bits [128]
+constexpr int SB_DZ3 = SB_FBITS + kBwdMaxSamples;           // dL/dz3 [4][128]
+constexpr int SB_WMAX = SB_DZ3 + 4 * kBwdMaxSamples;        // multiply_density_with_triplane_wieght: max part weight [128]
+constexpr int SB_KMAX = SB_WMAX + kBwdMaxSamples;           //   the part that attains it [128] (ints)
+constexpr int SB_GWM = SB_KMAX + kBwdMaxSamples;            //   dL/d(max weight) [128]
+constexpr int SB_QUEUE = SB_GWM + kBwdMaxSamples;           // 2 ray slots
+constexpr int kBwdScratchFloats = SB_QUEUE + 64;
 static_assert(SB_QUEUE + kQueueLdsInts <= kBwdScratchFloats, "scratch overflow");
 
 constexpr int kTRow = 33;                       // floats per texel row of the transpose tile (32 + 1 pad)
@@ -133,8 +137,10 @@ struct BwdTile {
 // F1, gather half: cube tests over the candidate parts, then the weighted features of the valid pairs (gather layout:
 // lane = 4 sample + chunk), exactly as the forward computes them
 __device__ __forceinline__ void bwd_gather_tile(const QueryCtx &S, const BwdTile &T, const int *l_cand, int ncand, float px,
-                                                float py, float pz, bool active, int lane, uint32_t &bits, float feat[8]) {
+                                                float py, float pz, bool active, int lane, uint32_t &bits, float feat[8],
+                                                float &wmax, int &kmax) {
     const int g4 = lane & 3;
+    wmax = 0.0f; kmax = -1;            // max over the valid parts of the part probability and the (first) part that attains it
     {
         uint32_t mine = 0;
         for (int i0 = 0; i0 < ncand; i0 += 4) {
@@ -186,6 +192,7 @@ __device__ __forceinline__ void bwd_gather_tile(const QueryCtx &S, const BwdTile
                 tap4(featg + 2 * T.fplane, t2, s2);
 #pragma unroll
                 for (int c = 0; c < 8; ++c) feat[c] += ((s0[c] + s1[c]) + s2[c]) * wk;
+                if (wk > wmax) { wmax = wk; kmax = k; }
             }
         }
     }
@@ -193,9 +200,10 @@ __device__ __forceinline__ void bwd_gather_tile(const QueryCtx &S, const BwdTile
 
 // F3 + F4: MLP backward of one 16-sample tile (dz3v: this lane's dL/dz3 in MFMA layout), row export for the weight
 // gradients, and the second pass over the pairs: d part-probability and d feature texels
+// gwm / kmax (gather layout, quad-uniform): multiply_density_with_triplane_wieght sends dL/d(max part weight) to that part
 __device__ __forceinline__ void bwd_backward_tile(const QueryCtx &S, const BwdTile &T, int b, float px, float py, float pz,
                                                   uint32_t bits, const f32x4 a1[4], const f32x4 a2[4], const float x[8],
-                                                  float dz3v, int lane) {
+                                                  float dz3v, int lane, float gwm = 0.0f, int kmax = -1) {
     const int g4 = lane & 3, j4 = lane >> 2;
     const int mj = lane & 15, mg = lane >> 4;          // MFMA layout: point mj, k-group mg
     f32x4 dz2[4], dz1[4];
@@ -266,6 +274,7 @@ __device__ __forceinline__ void bwd_backward_tile(const QueryCtx &S, const BwdTi
         }
         dot += quad_perm_f<0xB1>(dot);
         dot += quad_perm_f<0x4E>(dot);                                  // d loss / d w_k, quad-uniform
+        if (act && k == kmax) dot += gwm;                               // density = MyReLU(.) * 10 * max_k w_k (narf.py:271-272)
         {   // w = s0 s1 s2, s = sigmoid(m): dw/dm_g = w (1 - s_g); lane g adds into the four taps of its plane
             const bool mon = act && g4 < 3 && !(ENARF_BWD_ABLATE & 2) && !(S.uniform_w > 0.0f);     // uniform weights: no plane gradient
             const float gm = mon ? dot * wp * (1.0f - sg) : 0.0f;
@@ -300,6 +309,10 @@ __device__ __forceinline__ void bwd_stage_image(const void *mlp_pack, const floa
     }
 }
 
+// SPL = fine tiles per wave: 1 for Nf <= 64 (the activations of the tile stay in registers from F1 to F3), 2 for
+// 64 < Nf <= 128 (each wave owns tiles w and w + 4; F1 keeps only the heads, F3 RECOMPUTES the tile's forward - the gathers
+// of the fine pass run twice, which is cheaper than 80 more live registers per lane)
+template <int SPL>
 __global__ __launch_bounds__(256, kBwdWavesPerSimd) void render_bwd_kernel(const enarf_render_bwd_args a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -317,10 +330,12 @@ __global__ __launch_bounds__(256, kBwdWavesPerSimd) void render_bwd_kernel(const
     int b = -1;
     QueryCtx S;
     S.mlp = l_w; S.mlp_h = nullptr; S.bias = l_bias; S.parts = l_parts; S.canon = l_canon;
-    S.H = a.H; S.W = a.W; S.P = P; S.mult_w = 0;
+    S.H = a.H; S.W = a.W; S.P = P; S.mult_w = a.multiply_density_with_weight ? (a.uniform_part_weight ? 2 : 1) : 0;
     S.clamp_mask = a.clamp_mask; S.uniform_w = a.uniform_part_weight ? 1.0f / (float)P : 0.0f;
     int *l_cand = reinterpret_cast<int *>(scratch + SB_CAND) + wave * 32;
     float *l_fh = scratch + SB_FH, *l_dz3 = scratch + SB_DZ3;
+    float *l_wmax = scratch + SB_WMAX, *l_gwm = scratch + SB_GWM;
+    int *l_kmax = reinterpret_cast<int *>(scratch + SB_KMAX);
     float *ttile = scratch + kBwdScratchFloats + wave * kTTile;     // this wave's atomic-transpose tile
     uint32_t *l_fbits = reinterpret_cast<uint32_t *>(scratch + SB_FBITS);
     const int j4 = lane >> 2, g4 = lane & 3;
@@ -332,6 +347,7 @@ __global__ __launch_bounds__(256, kBwdWavesPerSimd) void render_bwd_kernel(const
     T.rows_dz1 = a.rows_dz1; T.rows_dz2 = a.rows_dz2; T.rows_dz3 = a.rows_dz3;
     T.rows_per_image = a.rows_per_image; T.row_blocks = a.row_blocks; T.ttile = ttile;
     T.gfeat = nullptr; T.gmask = nullptr;
+    constexpr int NS = kBwdMaxSamples;              // stride of the per-sample LDS arrays
 
     while (cur >= 0) {
         if (tid == 0) rq.pop(qslot ^ 1);
@@ -355,35 +371,43 @@ __global__ __launch_bounds__(256, kBwdWavesPerSimd) void render_bwd_kernel(const
         const float ex = exact_mul(dmax, dx_), ey = exact_mul(dmax, dy_), ez = exact_mul(dmax, dz_);
         const float *bins = a.bins + ((size_t)b * n + ray) * Nf;
 
-        // ---- F1: forward of this wave's fine samples (gather layout: lane = 4 sample + chunk)
-        const int i = wave * 16 + j4;                       // full tiles of 16 samples: Nf = 48 keeps wave 3 idle
-        const bool active = i < Nf - 1;
-        const float bi = bins[min(i, Nf - 1)];
-        const float px = exact_lerp(sx, ex, bi), py = exact_lerp(sy, ey, bi), pz = exact_lerp(sz, ez, bi);
-        uint32_t bits;
-        float feat[8];
-        bwd_gather_tile(S, T, l_cand, ncand, px, py, pz, active, lane, bits, feat);
-        const bool ran = __ballot(bits != 0) != 0;      // wave-uniform
-        f32x4 a1[4], a2[4], o;
+        // ---- F1: forward of this wave's fine tiles (gather layout: lane = 4 sample + chunk); full tiles of 16 samples
+        float px[SPL], py[SPL], pz[SPL];
+        uint32_t bits[SPL];
+        bool ran[SPL];
+        f32x4 a1[4], a2[4];        // SPL == 1: kept from F1 to F3
         float x[8];
-        if (ran) {
-            const int src = ((lane & 15) << 2) | (lane >> 4);
 #pragma unroll
-            for (int c = 0; c < 8; ++c) x[c] = __shfl(feat[c], src);
-            mlp_tile_f32_keep(l_w, l_bias, x, lane, a1, a2, o);
-        } else {
-            o = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int u = 0; u < SPL; ++u) {
+            const int base = (wave + 4 * u) * 16, i = base + j4;
+            const bool active = i < Nf - 1;
+            const float bi = bins[min(i, Nf - 1)];
+            px[u] = exact_lerp(sx, ex, bi); py[u] = exact_lerp(sy, ey, bi); pz[u] = exact_lerp(sz, ez, bi);
+            float feat[8], wmx;
+            int kmx;
+            bwd_gather_tile(S, T, l_cand, ncand, px[u], py[u], pz[u], active && base < Nf, lane, bits[u], feat, wmx, kmx);
+            ran[u] = __ballot(bits[u] != 0) != 0;      // wave-uniform
+            f32x4 o;
+            if (ran[u]) {
+                const int src = ((lane & 15) << 2) | (lane >> 4);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) x[c] = __shfl(feat[c], src);
+                if (SPL == 1) mlp_tile_f32_keep(l_w, l_bias, x, lane, a1, a2, o);
+                else o = mlp_tile_f32(l_w, l_bias, x, lane);
+            } else {
+                o = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            }
+            if (lane < 16 && base + lane < Nf) {
+                const int io = base + lane;
+                l_fh[io] = o[0]; l_fh[NS + io] = o[1]; l_fh[2 * NS + io] = o[2]; l_fh[3 * NS + io] = o[3];
+            }
+            if (i < Nf && g4 == 0) { l_fbits[i] = active ? bits[u] : 0u; l_wmax[i] = wmx; l_kmax[i] = kmx; }
         }
-        if (lane < 16 && wave * 16 + lane < Nf) {
-            const int io = wave * 16 + lane;
-            l_fh[io] = o[0]; l_fh[64 + io] = o[1]; l_fh[128 + io] = o[2]; l_fh[192 + io] = o[3];
-        }
-        if (i < Nf && g4 == 0) l_fbits[i] = active ? bits : 0u;
         __syncthreads();
         const int next_ray = rq.get(qslot ^ 1);
         qslot ^= 1;
 
-        // ---- F2 (wave 0, lane = sample): compositing backward -> dL/dz3
+        // ---- F2 (wave 0, element e = 64 s + lane): compositing backward -> dL/dz3 (and dL/d max part weight)
         if (wave == 0) {
             const size_t ro = (size_t)b * n + ray;
             const float gC0 = a.g_color ? a.g_color[((size_t)b * 3 + 0) * n + ray] : 0.0f;
@@ -391,40 +415,92 @@ __global__ __launch_bounds__(256, kBwdWavesPerSimd) void render_bwd_kernel(const
             const float gC2 = a.g_color ? a.g_color[((size_t)b * 3 + 2) * n + ray] : 0.0f;
             const float gM = a.g_mask ? a.g_mask[ro] : 0.0f;
             const float gD = a.g_disparity ? a.g_disparity[ro] : 0.0f;
-            const int ci = min(lane, Nf - 1);
-            const bool seg = lane < Nf - 1;
-            const uint32_t sb = l_fbits[ci];
-            const float h0 = l_fh[ci], h1 = l_fh[64 + ci], h2 = l_fh[128 + ci], h3 = l_fh[192 + ci];
-            const float den = seg ? density_head(h3, sb, 0.0f, 0, P) : 0.0f;
-            const float cr = tanhf(h0), cg = tanhf(h1), cb = tanhf(h2);
-            const float fdepth = exact_lerp(dmin, dmax, bins[ci]);
-            const float delta = __shfl_down(fdepth, 1) - fdepth;
-            const float aa = seg ? den * delta * a.render_scale : 0.0f;
-            const float cs = wave_scan_incl(aa, lane);
-            const float T = expf(-(cs - aa)), ea = expf(-aa);
-            const float wgt = seg ? T * (1.0f - ea) : 0.0f;
-            const float G = seg ? (gC0 * cr + gC1 * cg + gC2 * cb) + gM + gD / fdepth : 0.0f;
-            const float gw = G * wgt;
-            const float incl = wave_scan_incl(gw, lane);
-            const float suffix = __shfl(incl, 63) - incl;                     // sum_{j>i} G_j w_j
-            const float d_a = G * T * ea - suffix;                            // dL/d(sigma delta)
-            const float d_sigma = seg ? d_a * delta * a.render_scale : 0.0f;
-            // density = MyReLU(h3) * 10 * any_valid; MyReLU backward: slope 0.1 for x < 0 when the gradient is negative
-            const float gy = sb ? d_sigma * 10.0f : 0.0f;
-            const float gx = (h3 >= 0.0f) ? gy : ((gy < 0.0f) ? 0.1f * gy : 0.0f);
-            l_dz3[192 + lane] = seg ? gx * styled_act_grad(h3) : 0.0f;
-            l_dz3[lane] = seg ? (1.0f - cr * cr) * (wgt * gC0) * styled_act_grad(h0) : 0.0f;
-            l_dz3[64 + lane] = seg ? (1.0f - cg * cg) * (wgt * gC1) * styled_act_grad(h1) : 0.0f;
-            l_dz3[128 + lane] = seg ? (1.0f - cb * cb) * (wgt * gC2) * styled_act_grad(h2) : 0.0f;
+            float fdepth[SPL], dnext[SPL], aa[SPL], cs[SPL], gw[SPL], incl[SPL], G[SPL], Tt[SPL], ea[SPL], wgt[SPL];
+            float h0[SPL], h1[SPL], h2[SPL], h3[SPL], cr[SPL], cg[SPL], cb[SPL], wm[SPL];
+            uint32_t sb[SPL];
+#pragma unroll
+            for (int s = 0; s < SPL; ++s) {
+                const int e = 64 * s + lane, ci = min(e, Nf - 1);
+                sb[s] = l_fbits[ci];
+                h0[s] = l_fh[ci]; h1[s] = l_fh[NS + ci]; h2[s] = l_fh[2 * NS + ci]; h3[s] = l_fh[3 * NS + ci];
+                cr[s] = tanhf(h0[s]); cg[s] = tanhf(h1[s]); cb[s] = tanhf(h2[s]);
+                fdepth[s] = exact_lerp(dmin, dmax, bins[ci]);
+            }
+            wv_next<SPL>(fdepth, dnext, lane);
+#pragma unroll
+            for (int s = 0; s < SPL; ++s) {
+                const int e = 64 * s + lane;
+                const bool seg = e < Nf - 1;
+                const float den = seg ? density_head(h3[s], sb[s], l_wmax[min(e, Nf - 1)], S.mult_w, P) : 0.0f;
+                aa[s] = seg ? den * (dnext[s] - fdepth[s]) * a.render_scale : 0.0f;
+                cs[s] = aa[s];
+            }
+            wv_scan_incl<SPL>(cs, lane);
+#pragma unroll
+            for (int s = 0; s < SPL; ++s) {
+                const bool seg = 64 * s + lane < Nf - 1;
+                Tt[s] = expf(-(cs[s] - aa[s])); ea[s] = expf(-aa[s]);
+                wgt[s] = seg ? Tt[s] * (1.0f - ea[s]) : 0.0f;
+                G[s] = seg ? (gC0 * cr[s] + gC1 * cg[s] + gC2 * cb[s]) + gM + gD / fdepth[s] : 0.0f;
+                gw[s] = G[s] * wgt[s];
+                incl[s] = gw[s];
+            }
+            wv_scan_incl<SPL>(incl, lane);
+            const float total = __shfl(incl[SPL - 1], 63);
+#pragma unroll
+            for (int s = 0; s < SPL; ++s) {
+                const int e = 64 * s + lane;
+                const bool seg = e < Nf - 1;
+                const float suffix = total - incl[s];                                   // sum_{j>i} G_j w_j
+                const float d_a = G[s] * Tt[s] * ea[s] - suffix;                        // dL/d(sigma delta)
+                const float d_sigma = seg ? d_a * (dnext[s] - fdepth[s]) * a.render_scale : 0.0f;
+                // density = MyReLU(h3) * 10 [* max part weight] * any_valid; MyReLU backward: slope 0.1 for x < 0 when the
+                // incoming gradient is negative (activation.py:12-16)
+                float scale10 = 10.0f, g_wm = 0.0f;
+                if (S.mult_w) {
+                    const float wmx = l_wmax[min(e, Nf - 1)];
+                    const bool all_valid = __popc(sb[s]) >= P;
+                    const float w_eff = (S.mult_w == 2) ? 1.0f / (float)P : (all_valid ? wmx : fmaxf(wmx, 0.125f));
+                    scale10 = 10.0f * w_eff;
+                    // the max is a valid part's weight (not the 0.125 of an invalid one, not the constant 1 / P)
+                    if (S.mult_w == 1 && sb[s] && (all_valid || wmx >= 0.125f)) g_wm = d_sigma * fmaxf(h3[s], 0.0f) * 10.0f;
+                }
+                const float gy = sb[s] ? d_sigma * scale10 : 0.0f;
+                const float gx = (h3[s] >= 0.0f) ? gy : ((gy < 0.0f) ? 0.1f * gy : 0.0f);
+                if (e < NS) {
+                    l_dz3[3 * NS + e] = seg ? gx * styled_act_grad(h3[s]) : 0.0f;
+                    l_dz3[e] = seg ? (1.0f - cr[s] * cr[s]) * (wgt[s] * gC0) * styled_act_grad(h0[s]) : 0.0f;
+                    l_dz3[NS + e] = seg ? (1.0f - cg[s] * cg[s]) * (wgt[s] * gC1) * styled_act_grad(h1[s]) : 0.0f;
+                    l_dz3[2 * NS + e] = seg ? (1.0f - cb[s] * cb[s]) * (wgt[s] * gC2) * styled_act_grad(h2[s]) : 0.0f;
+                    l_gwm[e] = seg ? g_wm : 0.0f;
+                }
+                (void)wm;
+            }
         }
         __syncthreads();
 
-        // ---- F3 + F4: MLP backward and scatter, per wave (skipped when the tile has no valid sample: then dz3 = 0)
-        if (ran) {
+        // ---- F3 + F4: MLP backward and scatter, per tile (skipped when the tile has no valid sample: then dz3 = 0)
+#pragma unroll
+        for (int u = 0; u < SPL; ++u) {
+            if (!ran[u]) continue;
+            const int base = (wave + 4 * u) * 16;
+            if (SPL == 2) {          // recompute the tile's forward (features, activations)
+                float feat[8], wmx;
+                int kmx;
+                uint32_t bits2;
+                const int i = base + j4;
+                bwd_gather_tile(S, T, l_cand, ncand, px[u], py[u], pz[u], i < Nf - 1, lane, bits2, feat, wmx, kmx);
+                const int src = ((lane & 15) << 2) | (lane >> 4);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) x[c] = __shfl(feat[c], src);
+                f32x4 o;
+                mlp_tile_f32_keep(l_w, l_bias, x, lane, a1, a2, o);
+            }
             const int mj = lane & 15, mg = lane >> 4;          // MFMA layout: point mj, k-group mg
-            const int ms = min(wave * 16 + mj, Nf - 1);
-            const float dz3v = (wave * 16 + mj < Nf) ? l_dz3[mg * 64 + ms] : 0.0f;
-            bwd_backward_tile(S, T, b, px, py, pz, bits, a1, a2, x, dz3v, lane);
+            const int ms = min(base + mj, Nf - 1);
+            const float dz3v = (base + mj < Nf) ? l_dz3[mg * NS + ms] : 0.0f;
+            const int si = min(base + j4, Nf - 1);             // gather layout: this quad's sample
+            bwd_backward_tile(S, T, b, px[u], py[u], pz[u], bits[u], a1, a2, x, dz3v, lane, l_gwm[si], l_kmax[si]);
         }
         // the next ray's first barrier orders this ray's LDS reads (l_dz3, l_fh) before their next writes
         __syncthreads();
@@ -446,12 +522,14 @@ __global__ __launch_bounds__(256, kBwdWavesPerSimd) void query_bwd_kernel(const 
     float *l_canon = l_parts + P * kLdsPartStride, *scratch = l_canon + P * kLdsCanonStride;
     QueryCtx S;
     S.mlp = l_w; S.mlp_h = nullptr; S.bias = l_bias; S.parts = l_parts; S.canon = l_canon;
-    S.H = a.H; S.W = a.W; S.P = P; S.mult_w = 0;
+    S.H = a.H; S.W = a.W; S.P = P; S.mult_w = a.multiply_density_with_weight ? (a.uniform_part_weight ? 2 : 1) : 0;
     S.clamp_mask = a.clamp_mask; S.uniform_w = a.uniform_part_weight ? 1.0f / (float)P : 0.0f;
     S.feat = a.feat_cl + (size_t)b * a.feat_batch_stride;
     S.mask = a.mask_planes + (size_t)b * a.mask_batch_stride;
     int *l_cand = reinterpret_cast<int *>(scratch + SB_CAND);
     float *l_fh = scratch + SB_FH, *l_dz3 = scratch + SB_DZ3;
+    float *l_wmax = scratch + SB_WMAX, *l_gwm = scratch + SB_GWM;
+    int *l_kmax = reinterpret_cast<int *>(scratch + SB_KMAX);
     uint32_t *l_fbits = reinterpret_cast<uint32_t *>(scratch + SB_FBITS);
     BwdTile T;
     T.H = a.H; T.W = a.W; T.mplane = (size_t)a.H * a.W; T.fplane = T.mplane * kFeat; T.l_wt = l_wt;
@@ -473,7 +551,9 @@ __global__ __launch_bounds__(256, kBwdWavesPerSimd) void query_bwd_kernel(const 
         const float px = pp[ic], py = pp[N + ic], pz = pp[2 * N + ic];
         uint32_t bits;
         float feat[8];
-        bwd_gather_tile(S, T, l_cand, P, px, py, pz, active, lane, bits, feat);
+        float wmx;
+        int kmx;
+        bwd_gather_tile(S, T, l_cand, P, px, py, pz, active, lane, bits, feat, wmx, kmx);
         const bool ran = tile * 64 + wave * 16 < N;        // wave-uniform: the tile has points (valid part or not)
         f32x4 a1[4], a2[4], o;
         float x[8];
@@ -489,7 +569,7 @@ __global__ __launch_bounds__(256, kBwdWavesPerSimd) void query_bwd_kernel(const 
             const int io = wave * 16 + lane;
             l_fh[io] = o[0]; l_fh[64 + io] = o[1]; l_fh[128 + io] = o[2]; l_fh[192 + io] = o[3];
         }
-        if (g4 == 0) l_fbits[wave * 16 + j4] = active ? bits : 0u;
+        if (g4 == 0) { l_fbits[wave * 16 + j4] = active ? bits : 0u; l_wmax[wave * 16 + j4] = wmx; l_kmax[wave * 16 + j4] = kmx; }
         __syncthreads();
         if (wave == 0) {   // head backward, lane = point of the tile
             const long long pi = tile * 64 + lane;
@@ -503,7 +583,15 @@ __global__ __launch_bounds__(256, kBwdWavesPerSimd) void query_bwd_kernel(const 
             const float h0 = l_fh[lane], h1 = l_fh[64 + lane], h2 = l_fh[128 + lane], h3 = l_fh[192 + lane];
             const float cr = tanhf(h0), cg = tanhf(h1), cb = tanhf(h2);
             // density = MyReLU(h3) * 10 * any_valid; MyReLU backward: slope 0.1 for x < 0 when the gradient is negative
-            const float gy = sb ? gD * 10.0f : 0.0f;
+            float scale10 = 10.0f, g_wm = 0.0f;
+            if (S.mult_w) {      // density = MyReLU(h3) * 10 * max_k w_k (narf.py:271-272); invalid parts weigh 0.125, no_selector 1 / P
+                const float wmx_ = l_wmax[lane];
+                const bool all_valid = __popc(sb) >= P;
+                scale10 = 10.0f * ((S.mult_w == 2) ? 1.0f / (float)P : (all_valid ? wmx_ : fmaxf(wmx_, 0.125f)));
+                if (S.mult_w == 1 && sb && (all_valid || wmx_ >= 0.125f)) g_wm = gD * fmaxf(h3, 0.0f) * 10.0f;
+            }
+            l_gwm[lane] = g_wm;
+            const float gy = sb ? gD * scale10 : 0.0f;
             const float gx = (h3 >= 0.0f) ? gy : ((gy < 0.0f) ? 0.1f * gy : 0.0f);
             l_dz3[192 + lane] = gx * styled_act_grad(h3);
             l_dz3[lane] = (1.0f - cr * cr) * gC0 * styled_act_grad(h0);
@@ -514,7 +602,7 @@ __global__ __launch_bounds__(256, kBwdWavesPerSimd) void query_bwd_kernel(const 
         if (ran) {
             const int mj = lane & 15, mg = lane >> 4;
             const float dz3v = l_dz3[mg * 64 + wave * 16 + mj];
-            bwd_backward_tile(S, T, b, px, py, pz, bits, a1, a2, x, dz3v, lane);
+            bwd_backward_tile(S, T, b, px, py, pz, bits, a1, a2, x, dz3v, lane, l_gwm[wave * 16 + j4], l_kmax[wave * 16 + j4]);
         }
         __syncthreads();     // l_fh / l_dz3 are rewritten by the next tile
     }
@@ -734,7 +822,7 @@ using namespace enarf;
 
 extern "C" long long enarf_render_bwd_rows_per_image(int n, int Nf) {
     if (n <= 0 || Nf <= 0) return 0;
-    return (long long)n * 64;     // 4 tiles of 16 rows per ray at most
+    return (long long)n * (Nf > 64 ? 128 : 64);     // 16 rows per valid fine tile: 4 tiles per ray up to Nf 64, 8 up to 128
 }
 
 extern "C" int enarf_render_bwd(const enarf_render_bwd_args *args, enarf_stream_t stream) {
@@ -742,7 +830,7 @@ extern "C" int enarf_render_bwd(const enarf_render_bwd_args *args, enarf_stream_
     const enarf_render_bwd_args &a = *args;
     if (a.B <= 0 || a.n <= 0 || a.P <= 0 || a.P > ENARF_MAX_PARTS || a.H <= 0 || a.W <= 0)
         return host::fail(ENARF_ERR_ARG, "enarf_render_bwd: bad sizes");
-    if (a.Nf < 2 || a.Nf > 64) return host::fail(ENARF_ERR_UNSUPPORTED, "enarf_render_bwd: Nf=%d outside [2, 64]", a.Nf);
+    if (a.Nf < 2 || a.Nf > kBwdMaxSamples) return host::fail(ENARF_ERR_UNSUPPORTED, "enarf_render_bwd: Nf=%d outside [2, %d]", a.Nf, kBwdMaxSamples);
     if (!a.image_coord || !a.inv_intrinsics || !a.parts || !a.canonical_pose || !a.feat_cl || !a.mask_planes || !a.mlp_pack ||
         !a.bins || !a.grad_feat_cl || !a.grad_mask_planes || !a.rows_x || !a.rows_h1 || !a.rows_h2 || !a.rows_dz1 ||
         !a.rows_dz2 || !a.rows_dz3 || !a.row_blocks || !a.workspace)
@@ -764,7 +852,8 @@ extern "C" int enarf_render_bwd(const enarf_render_bwd_args *args, enarf_stream_
     long long wgs = (long long)num_cus * kBwdWavesPerSimd;
     const long long total = (long long)a.B * a.n;
     if (wgs > total) wgs = total;
-    hipLaunchKernelGGL(render_bwd_kernel, dim3((unsigned)wgs), dim3(256), (size_t)bwd_lds_floats(a.P) * 4, st, a);
+    if (a.Nf > 64) hipLaunchKernelGGL(render_bwd_kernel<2>, dim3((unsigned)wgs), dim3(256), (size_t)bwd_lds_floats(a.P) * 4, st, a);
+    else hipLaunchKernelGGL(render_bwd_kernel<1>, dim3((unsigned)wgs), dim3(256), (size_t)bwd_lds_floats(a.P) * 4, st, a);
     return host::check_launch("enarf_render_bwd");
 }
 

@@ -47,11 +47,11 @@ def density_volume(model, pose_to_camera: torch.Tensor, center: torch.Tensor, vo
     parts[:, :, 12] = (model.canonical_bone_length[:, None] / model_input["bone_length"] / model.coordinate_scale)[:, :, 0]
     tri, feat_cl = model._tri_plane_pair(model_input)
     pack = model._mlp_pack(model_input["z_rend"])
-    mult_w = bool(model.config.multiply_density_with_triplane_wieght)
+    flags = model.kernel_flags()
     total = D * D * D
     if chunk >= total and total < 2 ** 31:          # one launch, the lattice generated in the kernel (no point tensor)
         den, _ = ops.query_fwd(None, parts, model.canonical_pose, tri, feat_cl, pack, mlp_mode=model.mlp_mode,
-                               multiply_density_with_weight=mult_w, need_color=False,
+                               need_color=False, **flags,
                                grid=(D, center.reshape(3).tolist(), float(model.coordinate_scale)))
         return den.reshape(D, D, D)
     out = torch.empty(total, dtype=torch.float32, device=dev)
@@ -59,7 +59,7 @@ def density_volume(model, pose_to_camera: torch.Tensor, center: torch.Tensor, vo
         e = min(s + chunk, total)
         pts = _grid_chunk(D, s, e, center, float(model.coordinate_scale), dev)
         den, _ = ops.query_fwd(pts, parts, model.canonical_pose, tri, feat_cl, pack, mlp_mode=model.mlp_mode,
-                               multiply_density_with_weight=mult_w, need_color=False)
+                               need_color=False, **flags)
         out[s:e] = den.reshape(-1)
     return out.reshape(D, D, D)
 

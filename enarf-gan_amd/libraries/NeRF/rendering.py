@@ -41,7 +41,7 @@ class _RenderFunction(torch.autograd.Function):
         pack = k["pack_fn"](z_rend.detach(), {n: t.detach() for n, t in mlp.items()})
         out = ops.render_fwd(k["image_coord"], k["inv_intrinsics"], k["parts"], k["canonical_pose"], tri_c, feat_cl, pack,
                              k["Nc"], k["Nf"], render_scale=k["render_scale"], bins=k["bins"], seed=k["seed"],
-                             mlp_mode=k["mlp_mode"], return_bins=True)
+                             mlp_mode=k["mlp_mode"], return_bins=True, **k["flags"])
         bins_used = out.taps["bins"]
         ctx.k = k
         ctx.save_for_backward(tri_c, feat_cl, pack, bins_used, z_rend.detach(), *[p.detach() for p in params])
@@ -56,7 +56,7 @@ class _RenderFunction(torch.autograd.Function):
         mlp = {f"layers.{i}.{leaf}": params[4 * i + j] for i in range(3) for j, leaf in enumerate(_MLP_LEAVES)}
         grad_tri, dW, db = ops.render_bwd(k["image_coord"], k["inv_intrinsics"], k["parts"], k["canonical_pose"], tri_c,
                                           feat_cl, pack, k["Nf"], bins_used, g_color, g_mask, g_disp,
-                                          render_scale=k["render_scale"])
+                                          render_scale=k["render_scale"], **k["flags"])
         pg, dz = ops.prepare_bwd(z_rend, mlp, dW)
         grads = []
         for i in range(3):
@@ -77,7 +77,7 @@ class _RenderFunctionCL(torch.autograd.Function):
         pack = k["pack_fn"](z_rend.detach(), {n: t.detach() for n, t in mlp.items()})
         out = ops.render_fwd(k["image_coord"], k["inv_intrinsics"], k["parts"], k["canonical_pose"], tri_c, feat_c, pack,
                              k["Nc"], k["Nf"], render_scale=k["render_scale"], bins=k["bins"], seed=k["seed"],
-                             mlp_mode=k["mlp_mode"], return_bins=True)
+                             mlp_mode=k["mlp_mode"], return_bins=True, **k["flags"])
         bins_used = out.taps["bins"]
         ctx.k = k
         ctx.save_for_backward(tri_c, feat_c, pack, bins_used, z_rend.detach(), *[p.detach() for p in params])
@@ -92,7 +92,7 @@ class _RenderFunctionCL(torch.autograd.Function):
         mlp = {f"layers.{i}.{leaf}": params[4 * i + j] for i in range(3) for j, leaf in enumerate(_MLP_LEAVES)}
         grad_tri, dW, db, gfeat = ops.render_bwd(k["image_coord"], k["inv_intrinsics"], k["parts"], k["canonical_pose"],
                                                  tri_c, feat_c, pack, k["Nf"], bins_used, g_color, g_mask, g_disp,
-                                                 render_scale=k["render_scale"], feat_grad_channel_last=True)
+                                                 render_scale=k["render_scale"], feat_grad_channel_last=True, **k["flags"])
         pg, dz = ops.prepare_bwd(z_rend, mlp, dW)
         grads = []
         for i in range(3):
@@ -138,12 +138,11 @@ def render(model, image_coord: torch.Tensor, pose_to_camera: torch.Tensor, inv_i
     if needs_grad and return_intermediate:
         raise NotImplementedError("return_intermediate=True is served from the kernel's taps and is not differentiable; "
                                   "call it under torch.no_grad()")
+    flags = model.kernel_flags() if hasattr(model, "kernel_flags") else dict(multiply_density_with_weight=mult_w)
     if needs_grad:
-        if mult_w:
-            raise NotImplementedError("backward with multiply_density_with_triplane_wieght is not implemented")
         k = dict(image_coord=image_coord.detach(), inv_intrinsics=inv_intrinsics.detach(), parts=_parts.detach(),
                  canonical_pose=model.canonical_pose, Nc=Nc, Nf=Nf, render_scale=float(render_scale), bins=bins, seed=seed,
-                 mlp_mode=model.mlp_mode, pack_fn=model._mlp_pack_from)
+                 mlp_mode=model.mlp_mode, pack_fn=model._mlp_pack_from, flags=flags)
         flat = [params[f"layers.{i}.{leaf}"] for i in range(3) for leaf in _MLP_LEAVES]
         if cl_route:
             color, mask, disparity, fw, fd, bins_used = _RenderFunctionCL.apply(k, tri_graph, feat_graph, z_rend, *flat)
@@ -157,7 +156,7 @@ def render(model, image_coord: torch.Tensor, pose_to_camera: torch.Tensor, inv_i
         _pack = model._mlp_pack(z_rend)
     out = ops.render_fwd(image_coord, inv_intrinsics, _parts, model.canonical_pose, tri, feat_cl, _pack, Nc, Nf,
                          render_scale=render_scale, bins=bins, seed=seed, mlp_mode=model.mlp_mode,
-                         multiply_density_with_weight=mult_w, return_bins=True, debug=return_intermediate)
+                         return_bins=True, debug=return_intermediate, **flags)
     model.buffers_tensors["bins"] = out.taps["bins"]
     model.buffers_tensors["fine_weights"] = out.fine_weights      # (B, 1, n, Nf-1); zeros for dropped rays
     model.buffers_tensors["fine_depth"] = out.fine_depth          # (B, 1, n, Nf)

@@ -81,9 +81,11 @@ class TriPlaneNARF(nn.Module):
         if view_dependent:
             raise NotImplementedError("view-dependent colour (no_ray_direction: False) is not on the shipped tri-plane "
                                       "path (configs set no_ray_direction: True / GAN) and is not implemented")
-        for flag in ("selector_mlp", "no_selector", "clamp_mask"):
-            if getattr(config, flag, False):
-                raise NotImplementedError(f"nerf_params.{flag}=True is not implemented by the HIP kernels")
+        if getattr(config, "selector_mlp", False):
+            raise NotImplementedError("nerf_params.selector_mlp=True (a learned per-part selector network instead of the "
+                                      "part-probability planes, models/narf.py:59-70) is not implemented by the HIP kernels")
+        self.no_selector = bool(getattr(config, "no_selector", False))          # uniform part weights (narf.py:133-134)
+        self.clamp_mask = bool(getattr(config, "clamp_mask", False))            # sampling.py:46-47
         self.config = config
         self.tri_plane_based = True
         self.w_dim, self.feat_dim = 512, 32
@@ -250,6 +252,11 @@ class TriPlaneNARF(nn.Module):
                                                  model_input.get("truncation_psi", 1))
         return tri
 
+    def kernel_flags(self) -> Dict[str, bool]:
+        """nerf_params switches the kernels take (forward and backward)"""
+        return dict(multiply_density_with_weight=bool(self.config.multiply_density_with_triplane_wieght),
+                    clamp_mask=self.clamp_mask, uniform_part_weight=self.no_selector)
+
     def _mlp_pack(self, z_rend: torch.Tensor) -> torch.Tensor:
         return self._mlp_pack_from(z_rend, self.mlp.as_dict())
 
@@ -305,16 +312,14 @@ class TriPlaneNARF(nn.Module):
         params = self.mlp.as_dict()
         if torch.is_grad_enabled() and (tri_graph.requires_grad or z_rend.requires_grad or
                                         any(p.requires_grad for p in params.values())):
-            if mult_w:
-                raise NotImplementedError("backward with multiply_density_with_triplane_wieght is not implemented")
             k = dict(points=position.detach(), parts=parts, canonical_pose=self.canonical_pose, mlp_mode=self.mlp_mode,
-                     pack_fn=self._mlp_pack_from)
+                     pack_fn=self._mlp_pack_from, flags=self.kernel_flags())
             flat = [params[f"layers.{i}.{leaf}"] for i in range(3) for leaf in _MLP_LEAVES]
             return _QueryFunction.apply(k, tri_graph, z_rend, *flat)
         tri, feat_cl = self._tri_plane_pair(model_input)
         pack = self._mlp_pack(z_rend)
         den, col, vb = ops.query_fwd(position, parts, self.canonical_pose, tri, feat_cl, pack, mlp_mode=self.mlp_mode,
-                                     multiply_density_with_weight=mult_w, need_valid=True)
+                                     need_valid=True, **self.kernel_flags())
         if not self.training:
             self.temporal_state["valid_bits"] = vb
         return den, col
@@ -384,7 +389,8 @@ class _QueryFunction(torch.autograd.Function):
         tri_c = tri.detach().contiguous()
         feat_cl = ops.triplane_pack(tri_c)
         pack = k["pack_fn"](z_rend.detach(), {n: t.detach() for n, t in mlp.items()})
-        den, col = ops.query_fwd(k["points"], k["parts"], k["canonical_pose"], tri_c, feat_cl, pack, mlp_mode=k["mlp_mode"])
+        den, col = ops.query_fwd(k["points"], k["parts"], k["canonical_pose"], tri_c, feat_cl, pack, mlp_mode=k["mlp_mode"],
+                                 **k["flags"])
         ctx.k = k
         ctx.save_for_backward(tri_c, feat_cl, pack, z_rend.detach(), *[p.detach() for p in params])
         return den, col
@@ -395,7 +401,8 @@ class _QueryFunction(torch.autograd.Function):
         tri_c, feat_cl, pack, z_rend = ctx.saved_tensors[:4]
         params = ctx.saved_tensors[4:]
         mlp = {f"layers.{i}.{leaf}": params[4 * i + j] for i in range(3) for j, leaf in enumerate(_MLP_LEAVES)}
-        grad_tri, dW, db = ops.query_bwd(k["points"], k["parts"], k["canonical_pose"], tri_c, feat_cl, pack, g_den, g_col)
+        grad_tri, dW, db = ops.query_bwd(k["points"], k["parts"], k["canonical_pose"], tri_c, feat_cl, pack, g_den, g_col,
+                                         **k["flags"])
         pg, dz = ops.prepare_bwd(z_rend, mlp, dW)
         grads = []
         for i in range(3):

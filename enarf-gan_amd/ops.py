@@ -579,7 +579,8 @@ def render_step_fwd(*args, **kw) -> RenderOutputs:
 @_on_tensor_device
 def render_bwd(image_coord, inv_intrinsics, parts, canonical_pose, tri_nchw, feat_cl, mlp_pack, Nf, bins,
                g_color, g_mask, g_disparity=None, render_scale: float = 1.0, drop_invalid_rays: Optional[bool] = None,
-               feat_grad_channel_last: bool = False, clamp_mask: bool = False, uniform_part_weight: bool = False):
+               feat_grad_channel_last: bool = False, clamp_mask: bool = False, uniform_part_weight: bool = False,
+               multiply_density_with_weight: bool = False):
     """Backward of render_fwd w.r.t. the tri-plane and the per-image demodulated MLP weights / biases.
 
     Returns (grad_tri (same batch as tri_nchw: 1 for a shared tri-plane), dW [3 x (B,out,in)], db [3 x (out,)]).
@@ -607,6 +608,7 @@ def render_bwd(image_coord, inv_intrinsics, parts, canonical_pose, tri_nchw, fea
     a.drop_invalid_rays = int(B == 1 if drop_invalid_rays is None else drop_invalid_rays)
     a.render_scale = float(render_scale)
     a.clamp_mask, a.uniform_part_weight = int(bool(clamp_mask)), int(bool(uniform_part_weight))
+    a.multiply_density_with_weight = int(bool(multiply_density_with_weight))
     a.image_coord, a.inv_intrinsics, a.parts = _p(coord), _p(Ki), _p(parts)
     a.canonical_pose = _p(_dev_f32(canonical_pose, "canonical_pose"))
     a.feat_cl, a.feat_batch_stride = _p(feat_cl), fstride
@@ -660,7 +662,7 @@ def _weight_grad(bufs, blocks, B: int, rows: int, dev: torch.device):
 
 @_on_tensor_device
 def query_bwd(points, parts, canonical_pose, tri_nchw, feat_cl, mlp_pack, g_density, g_color, clamp_mask: bool = False,
-              uniform_part_weight: bool = False):
+              uniform_part_weight: bool = False, multiply_density_with_weight: bool = False):
     """Backward of query_fwd w.r.t. the tri-plane and the per-image demodulated MLP weights / biases.
 
     points (B,3,N); g_density (B,1,N) or None; g_color (B,3,N) or None. Returns (grad_tri, dW [3 x (B,out,in)], db)."""
@@ -679,6 +681,7 @@ def query_bwd(points, parts, canonical_pose, tri_nchw, feat_cl, mlp_pack, g_dens
     a = _lib.QueryBwdArgs()
     a.B, a.P, a.H, a.W, a.N = B, P, H, W, N
     a.clamp_mask, a.uniform_part_weight = int(bool(clamp_mask)), int(bool(uniform_part_weight))
+    a.multiply_density_with_weight = int(bool(multiply_density_with_weight))
     a.points, a.parts = _p(pts) if N else _p(torch.zeros(1, device=dev)), _p(parts)
     a.canonical_pose = _p(_dev_f32(canonical_pose, "canonical_pose"))
     a.feat_cl, a.feat_batch_stride = _p(feat_cl), fstride

@@ -260,7 +260,7 @@ int enarf_render_step_fwd(const enarf_prepare_args *prep, const float *tri_nchw,
 /* ---------------------------------------------------------------------------------------------
  * Backward of the fused renderer: what `loss_gen.backward()` computes through render
  * (libraries/NeRF/rendering.py:283-335), the fine-pass query (models/narf.py:176-275), the StyledMLP and MyReLU's
- * custom backward (libraries/NeRF/activation.py:12-16). As in the reference, gradients flow through the FINE pass
+ * custom backward (libraries/NeRF/activation.py:12-16). Nf <= 128. As in the reference, gradients flow through the FINE pass
  * only (the importance samples are not differentiable) and not into poses.
  *   enarf_render_bwd   d loss / d tri-plane (atomically accumulated into caller-zeroed buffers) and, per valid
  *                      16-sample tile, the rows (x, h1, h2, dz1, dz2, dz3) from which the caller forms the weight
@@ -286,6 +286,8 @@ typedef struct {
     unsigned int *row_blocks;             /* device (B,): 16-row blocks written per image (zeroed by the call) */
     void *workspace;                      /* as enarf_render_fwd */
     int clamp_mask, uniform_part_weight;  /* as in enarf_query_args (clamp_mask: straight-through gradient, sampling.py:46-47) */
+    int multiply_density_with_weight;     /* nerf_params.multiply_density_with_triplane_wieght: the gradient also reaches the
+                                             part probability that attains the maximum (models/narf.py:271-272) */
 } enarf_render_bwd_args;
 
 long long enarf_render_bwd_rows_per_image(int n, int Nf);
@@ -311,7 +313,7 @@ typedef struct {
     float *rows_x, *rows_h1, *rows_h2, *rows_dz1, *rows_dz2, *rows_dz3;   /* (B, rows_per_image, 32|64|64|64|64|4) */
     long long rows_per_image;             /* >= enarf_query_bwd_rows_per_image(N) */
     unsigned int *row_blocks;             /* device (B,): 16-row blocks written per image (zeroed by the call) */
-    int clamp_mask, uniform_part_weight;
+    int clamp_mask, uniform_part_weight, multiply_density_with_weight;
 } enarf_query_bwd_args;
 long long enarf_query_bwd_rows_per_image(long long N);
 int enarf_query_bwd(const enarf_query_bwd_args *args, enarf_stream_t stream);

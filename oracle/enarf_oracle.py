@@ -216,8 +216,8 @@ def part_prob(mask_planes: torch.Tensor, canonical: torch.Tensor, valid: torch.T
                     v = F.grid_sample(planes[p][None, None], grid, align_corners=False)[0, 0, :, 0]
                 else:
                     v = sample_plane(planes[p][None], pos[p], pos[(p + 1) % 3])[0]
-                if clamp_mask:
-                    v = v.clamp(-2, 5)
+                if clamp_mask:      # value clamped, gradient straight through (sampling.py:46-47)
+                    v = (v.detach().clamp(-2, 5) - v.detach()) + v
                 s = torch.sigmoid(v)
                 prod = s if prod is None else prod * s
             w[b, k] = prod
@@ -294,7 +294,8 @@ class MyReLU(torch.autograd.Function):
 def query(points: torch.Tensor, pose_scaled: torch.Tensor, scale: torch.Tensor,
           canonical_pose: torch.Tensor, tri_plane: torch.Tensor,
           weights: List[Tuple[torch.Tensor, torch.Tensor]], use_grid_sample: bool = False,
-          multiply_density_with_weight: bool = False, return_taps: bool = False):
+          multiply_density_with_weight: bool = False, return_taps: bool = False, clamp_mask: bool = False,
+          no_selector: bool = False):
     """calc_density_and_color_from_camera_coord_v2 (narf.py:176-211) + backbone (:213-275).
 
     points (B,3,N) camera coords in the scaled space; pose_scaled (B,P,4,4).
@@ -302,7 +303,10 @@ def query(points: torch.Tensor, pose_scaled: torch.Tensor, scale: torch.Tensor,
     local, canonical = to_local_and_canonical(points, pose_scaled, scale, canonical_pose)
     valid = validity(local, canonical)
     P = pose_scaled.shape[1]
-    w = part_prob(tri_plane[:, 3 * FEAT_DIM:], canonical, valid, use_grid_sample)
+    if no_selector:          # models/narf.py:133-134: every entry of the weight tensor is 1 / P
+        w = torch.full(valid.shape, 1.0 / P, dtype=points.dtype)
+    else:
+        w = part_prob(tri_plane[:, 3 * FEAT_DIM:], canonical, valid, use_grid_sample, clamp_mask)
     feat = weighted_feature(tri_plane[:, :3 * FEAT_DIM], canonical, w, valid, use_grid_sample)
     h = styled_mlp(feat, weights)
     color = torch.tanh(h[:, :3])
@@ -447,7 +451,8 @@ def render(image_coord: torch.Tensor, pose_parts: torch.Tensor, bone_length_part
            tri_plane: torch.Tensor, mlp: Dict[str, torch.Tensor], z_rend: torch.Tensor,
            coordinate_scale: float = 3.0, Nc: int = 48, Nf: int = 64, render_scale: float = 1.0,
            bins: Optional[torch.Tensor] = None, generator: Optional[torch.Generator] = None,
-           use_grid_sample: bool = False, return_taps: bool = False):
+           use_grid_sample: bool = False, return_taps: bool = False, multiply_density_with_weight: bool = False,
+           clamp_mask: bool = False, no_selector: bool = False):
     """render() (rendering.py:227-359) after transform_pose: pose_parts (B,P,4,4) unscaled.
 
     `bins` (B,n,Nf), sorted, replaces the random importance samples (for parity runs); rays that
@@ -465,8 +470,9 @@ def render(image_coord: torch.Tensor, pose_parts: torch.Tensor, bone_length_part
     drop = (~rvalid) if B == 1 else torch.zeros_like(rvalid)
 
     cdepth, cpts, start, end = coarse_points(rd, dmin, dmax, Nc)
+    qkw = dict(multiply_density_with_weight=multiply_density_with_weight, clamp_mask=clamp_mask, no_selector=no_selector)
     cden, _, cvalid = query(cpts.reshape(B, 3, -1), pose, scale, canonical_pose, tri_plane.to(dt), weights,
-                            use_grid_sample)
+                            use_grid_sample, **qkw)
     cden = cden.reshape(B, n, Nc)
     _, cw = ray_weights(cden, cdepth, render_scale)
     cws = smooth_weights(cw)
@@ -474,7 +480,7 @@ def render(image_coord: torch.Tensor, pose_parts: torch.Tensor, bone_length_part
         bins = draw_bins(cws, Nf, Nc, generator)
     fdepth, fpts = fine_points(bins.to(dt), dmin, dmax, start, end)
     fden, fcol, fvalid = query(fpts.reshape(B, 3, -1), pose, scale, canonical_pose, tri_plane.to(dt), weights,
-                               use_grid_sample)
+                               use_grid_sample, **qkw)
     fden = fden.reshape(B, n, Nf)
     fcol = fcol.reshape(B, 3, n, Nf)
     rc, rm, rdisp, fw = composite(fden, fcol, fdepth, render_scale)

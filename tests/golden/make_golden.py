@@ -136,17 +136,19 @@ class Cfg(dict):
     __setattr__ = dict.__setitem__
 
 
-def nerf_cfg(origin_location, Nc, Nf):
-    return Cfg(hidden_size=32, Nc=Nc, Nf=Nf, origin_location=origin_location, coordinate_scale=3,
+def nerf_cfg(origin_location, Nc, Nf, **over):
+    c = Cfg(hidden_size=32, Nc=Nc, Nf=Nf, origin_location=origin_location, coordinate_scale=3,
                render_bs=16384, no_ray_direction=True, multiply_density_with_triplane_wieght=False,
                clamp_mask=False, constant_triplane=True, constant_trimask=False,
                constant_trimask_lr_mul=1, deformation_field=False, selector_mlp=False,
                no_selector=False, time_conditional=True, pose_conditional=False, mask_input=False)
+    c.update(over)
+    return c
 
 
-def build_reference_model(scene, Nc, Nf, style_dim):
+def build_reference_model(scene, Nc, Nf, style_dim, **cfg_over):
     from models.narf import TriPlaneNARF
-    cfg = nerf_cfg(scene["origin_location"], Nc, Nf)
+    cfg = nerf_cfg(scene["origin_location"], Nc, Nf, **cfg_over)
     model = TriPlaneNARF(cfg, z_dim=style_dim, num_bone=24, bone_length=True,
                          parent=scene["parents"], num_bone_param=23, view_dependent=False)
     model.register_canonical_pose(scene["canonical_pose"])
@@ -358,13 +360,18 @@ def run_sampling_case(name, seed):
     print(f"{name}: valid pairs {int(valid.sum())} -> {os.path.getsize(path) / 1024:.0f} KiB")
 
 
-def run_query_case(name, batch, n_points, origin_location, style_dim, seed):
-    """calc_density_and_color_from_camera_coord_v2 (models/narf.py:176) on a point cloud."""
+def run_query_case(name, batch, n_points, origin_location, style_dim, seed, mask_scale=1.0, **cfg_over):
+    """calc_density_and_color_from_camera_coord_v2 (models/narf.py:176) on a point cloud. cfg_over: nerf_params switches
+    (clamp_mask, no_selector, multiply_density_with_triplane_wieght); mask_scale stretches the part-probability planes so
+    that clamp_mask's [-2, 5] range is exercised."""
     from enarf_gan_amd import synth
     from libraries.NARF.pose_utils import transform_pose
     from libraries.NeRF.utils import in_cube
     scene = synth.make_scene(64, batch, origin_location, style_dim)
-    model = build_reference_model(scene, 48, 64, style_dim)
+    if mask_scale != 1.0:
+        scene["tri_plane"] = scene["tri_plane"].clone()
+        scene["tri_plane"][:, 96:] *= mask_scale
+    model = build_reference_model(scene, 48, 64, style_dim, **cfg_over)
     pose_p, bl_p = transform_pose(scene["pose_to_camera"], scene["bone_length"], origin_location,
                                   scene["parents"])
     pose_s = pose_p.clone()
@@ -384,7 +391,9 @@ def run_query_case(name, batch, n_points, origin_location, style_dim, seed):
     w = model.temporal_state["weight"]
     out = dict(batch=batch, n_points=n_points, origin_location=origin_location, style_dim=style_dim,
                points=pts.numpy(), density=den.numpy(), color=col.numpy(), valid=bitmask(v),
-               weight=w.numpy(), canonical=canon.numpy()[:, :, :, :256])
+               weight=w.numpy(), canonical=canon.numpy()[:, :, :, :256], mask_scale=mask_scale,
+               clamp_mask=bool(cfg_over.get("clamp_mask", False)), no_selector=bool(cfg_over.get("no_selector", False)),
+               mult_w=bool(cfg_over.get("multiply_density_with_triplane_wieght", False)))
     path = os.path.join(HERE, f"{name}.npz")
     np.savez_compressed(path, **out)
     print(f"{name}: valid pairs {int(v.sum())}, points with any valid {int(v.any(dim=1).sum())}/{batch * n_points}"
@@ -468,6 +477,12 @@ def main():
         run_render_case("render_c4s_32_b2", size=32, batch=2, Nc=72, Nf=96, origin_location="center_fixed",
                         style_dim=256, n_keep=96, seed=25)
         return
+    if "--only-modes" in sys.argv:
+        run_query_case("query_b1_clamp_multw", batch=1, n_points=2048, origin_location="center_fixed", style_dim=20, seed=7,
+                       mask_scale=3.0, clamp_mask=True, multiply_density_with_triplane_wieght=True)
+        run_query_case("query_b1_noselector", batch=1, n_points=2048, origin_location="center_fixed", style_dim=20, seed=8,
+                       no_selector=True, multiply_density_with_triplane_wieght=True)
+        return
     if "--only-sampling" in sys.argv:
         run_sampling_case("sampling_api", seed=51)
         return
@@ -505,6 +520,10 @@ def main():
     run_fullframe_case("full_gan_32_b2", size=32, batch=2, Nc=48, Nf=64, origin_location="center_fixed", style_dim=256)
     run_encoding_case("encoding", seed=41)
     run_sampling_case("sampling_api", seed=51)
+    run_query_case("query_b1_clamp_multw", batch=1, n_points=2048, origin_location="center_fixed", style_dim=20, seed=7,
+                   mask_scale=3.0, clamp_mask=True, multiply_density_with_triplane_wieght=True)
+    run_query_case("query_b1_noselector", batch=1, n_points=2048, origin_location="center_fixed", style_dim=20, seed=8,
+                   no_selector=True, multiply_density_with_triplane_wieght=True)
 
 
 if __name__ == "__main__":

@@ -242,3 +242,95 @@ def test_model_with_deformation_field_producer():
     ((color * gc.cuda()).sum() + (mask * gm.cuda()).sum()).backward()
     assert_close(m.tri_plane.grad.cpu(), o_tri, "tri_plane.grad through the warp", 1e-3)
     assert abs(float(fg.amp.grad) - float(o_amp)) < 2e-3 * max(abs(float(o_amp)), 1e-3), (float(fg.amp.grad), float(o_amp))
+
+
+def _oracle_grads_modes(sc, coord, Nc, Nf, bins, gc, gm, gd, **modes):
+    s = sc.raw
+    tri = s["tri_plane"].clone().requires_grad_(True)
+    mlp = {k: v.clone().requires_grad_(True) for k, v in s["mlp"].items() if "noise" not in k}
+    z = s["z_rend"].clone().requires_grad_(True)
+    rc, rm, rd = O.render(coord, sc.pose_parts, sc.bl_parts, s["inv_intrinsics"], sc.cpose, sc.cbl, tri, mlp, z,
+                          sc.cs, Nc, Nf, bins=bins, **modes)
+    loss = (rc * gc).sum() + (rm * gm).sum() + (rd * gd).sum()
+    keys = sorted(mlp)
+    grads = torch.autograd.grad(loss, [tri, z] + [mlp[k] for k in keys])
+    return (rc, rm, rd), grads[0], grads[1], dict(zip(keys, grads[2:]))
+
+
+@pytest.mark.parametrize("Nf,modes", [
+    (96, {}),                                                   # BASELINE config C4's fine count: two tiles per wave, recompute
+    (128, {}),
+    (72, dict(multiply_density_with_weight=True)),              # narf.py:271-272: gradient into the max part probability
+    (32, dict(multiply_density_with_weight=True, clamp_mask=True)),
+    (32, dict(no_selector=True, multiply_density_with_weight=True)),
+    (48, dict(clamp_mask=True)),
+])
+def test_render_backward_fine_counts_and_density_modes(Nf, modes):
+    """enarf_render_bwd beyond round 1's limits: 64 < Nf <= 128 (each wave owns two fine tiles and recomputes them for the
+    backward), multiply_density_with_triplane_wieght, clamp_mask (straight-through) and no_selector - forward values and
+    every gradient against autograd through the oracle with the same switches."""
+    from enarf_gan_amd import ops
+    sc = Scene(32, 1, "center_fixed", 20)
+    if modes.get("clamp_mask"):
+        sc.raw["tri_plane"] = sc.raw["tri_plane"].clone()
+        sc.raw["tri_plane"][:, 96:] *= 3.0                    # push plane samples beyond [-2, 5]
+    ds = DeviceScene(sc)
+    Nc, n_rays = 48, 40
+    start = 32 * 15
+    coord = sc.raw["image_coord"][..., start:start + n_rays].contiguous()
+    kflags = dict(multiply_density_with_weight=modes.get("multiply_density_with_weight", False),
+                  clamp_mask=modes.get("clamp_mask", False), uniform_part_weight=modes.get("no_selector", False))
+    fwd = ds.render(coord, Nc, Nf, None, seed=9, mlp_mode="f32", return_bins=True, **kflags)
+    bins = fwd.taps["bins"].cpu()
+    g = torch.Generator().manual_seed(Nf)
+    gc, gm, gd = torch.randn(1, 3, n_rays, generator=g), torch.randn(1, n_rays, generator=g), torch.randn(1, n_rays, generator=g)
+    (rc, rm, rd), o_tri, o_z, o_mlp = _oracle_grads_modes(sc, coord, Nc, Nf, bins, gc, gm, gd, **modes)
+    assert float(rm.max()) > 0.2
+    assert_close(fwd.color.cpu(), rc.detach(), "forward colour")
+    assert_close(fwd.mask.cpu(), rm.detach(), "forward mask")
+    grad_tri, dW, db = ops.render_bwd(coord.cuda(), ds.inv_K, ds.parts, ds.cpose, ds.tri, ds.feat_cl, ds.pack, Nf, bins.cuda(),
+                                      gc.cuda(), gm.cuda(), gd.cuda(), **kflags)
+    pg, dz = ops.prepare_bwd(sc.raw["z_rend"].cuda(), ds.mlp, dW)
+    assert_close(grad_tri[:, :96].cpu(), o_tri[:, :96], "d loss / d feature planes", 1e-3)
+    if modes.get("no_selector"):
+        assert float(o_tri[:, 96:].abs().max()) == 0.0 and float(grad_tri[:, 96:].abs().max()) == 0.0
+    else:
+        assert float(o_tri[:, 96:].abs().max()) > 0
+        assert_close(grad_tri[:, 96:].cpu(), o_tri[:, 96:], "d loss / d part-probability planes", 1e-3)
+    for l in range(3):
+        assert_close(db[l].cpu(), o_mlp[f"layers.{l}.bias"].reshape(-1), f"d bias {l}", 1e-3)
+        assert_close(pg[f"layers.{l}.conv.weight"].cpu(), o_mlp[f"layers.{l}.conv.weight"], f"d layers.{l}.conv.weight", 1e-3)
+    assert_close(dz.cpu(), o_z, "d z_rend", 1e-3)
+
+
+@pytest.mark.parametrize("name", ["query_b1_clamp_multw", "query_b1_noselector"])
+def test_query_modes_forward_and_backward(name):
+    """clamp_mask / multiply_density_with_triplane_wieght / no_selector in the point query: forward against the REFERENCE's
+    outputs (tests/golden, the reference run with those nerf_params), backward against autograd through the oracle."""
+    from _helpers import load_golden
+    from enarf_gan_amd import ops
+    g = load_golden(name)
+    sc = Scene(64, 1, "center_fixed", 20)
+    sc.raw["tri_plane"] = sc.raw["tri_plane"].clone()
+    sc.raw["tri_plane"][:, 96:] *= float(g["mask_scale"])
+    ds = DeviceScene(sc)
+    kflags = dict(multiply_density_with_weight=bool(g["mult_w"]), clamp_mask=bool(g["clamp_mask"]), uniform_part_weight=bool(g["no_selector"]))
+    pts = torch.from_numpy(g["points"])
+    den, col, vb = ds.query(pts, mlp_mode="f32", need_valid=True, **kflags)
+    same = vb.cpu().numpy().view(np.uint32) == g["valid"]
+    assert (~same).sum() <= 2
+    assert_close(den.cpu().numpy()[:, 0][same], g["density"][:, 0][same], "density vs reference")
+    assert_close(col.cpu().numpy().transpose(0, 2, 1)[same], g["color"].transpose(0, 2, 1)[same], "colour vs reference")
+    # backward on a subset
+    N = 600
+    p = pts[..., :N].contiguous()
+    gen = torch.Generator().manual_seed(2)
+    gd, gc = torch.randn(1, 1, N, generator=gen), torch.randn(1, 3, N, generator=gen)
+    tri = sc.raw["tri_plane"].clone().requires_grad_(True)
+    oden, ocol, _ = O.query(p, sc.pose_scaled, sc.scale, sc.cpose, tri, sc.weights(), multiply_density_with_weight=bool(g["mult_w"]),
+                            clamp_mask=bool(g["clamp_mask"]), no_selector=bool(g["no_selector"]))
+    (o_tri,) = torch.autograd.grad((oden * gd).sum() + (ocol * gc).sum(), [tri])
+    grad_tri, dW, db = ops.query_bwd(p.cuda(), ds.parts, ds.cpose, ds.tri, ds.feat_cl, ds.pack, gd.cuda(), gc.cuda(), **kflags)
+    assert_close(grad_tri[:, :96].cpu(), o_tri[:, :96], "query: d feature planes", 1e-3)
+    if not bool(g["no_selector"]):
+        assert_close(grad_tri[:, 96:].cpu(), o_tri[:, 96:], "query: d part-probability planes", 1e-3)

@@ -256,6 +256,9 @@ def test_unsupported_configs_raise():
     from enarf_gan_amd.models.narf import TriPlaneNARF
     with pytest.raises(NotImplementedError):
         TriPlaneNARF(_nerf_cfg(selector_mlp=True), 20, 24, parent=synth.SMPL_PARENTS)
+    m = TriPlaneNARF(_nerf_cfg(no_selector=True, clamp_mask=True, multiply_density_with_triplane_wieght=True), 20, 24,
+                     parent=synth.SMPL_PARENTS)
+    assert m.kernel_flags() == dict(multiply_density_with_weight=True, clamp_mask=True, uniform_part_weight=True)
     with pytest.raises(NotImplementedError):
         TriPlaneNARF(_nerf_cfg(), 20, 24, parent=synth.SMPL_PARENTS, view_dependent=True)
     m = TriPlaneNARF(_nerf_cfg(constant_triplane=False), 20, 24, parent=synth.SMPL_PARENTS)

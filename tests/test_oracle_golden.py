@@ -80,6 +80,29 @@ def test_query_matches_reference(golden_dir, name):
     _assert_close(den2, den, "density explicit vs grid_sample", 1e-5)
 
 
+@pytest.mark.parametrize("name", ["query_b1_clamp_multw", "query_b1_noselector"])
+def test_query_modes_match_reference(golden_dir, name):
+    """clamp_mask (sampling.py:46-47), multiply_density_with_triplane_wieght (narf.py:271-272) and no_selector (narf.py:133-134)
+    in the oracle against the reference run with those nerf_params."""
+    g = _load(golden_dir, name)
+    scene = synth.make_scene(64, 1, "center_fixed", 20)
+    scene["tri_plane"][:, 96:] *= float(g["mask_scale"])
+    pose_p, bl_p = O.transform_pose(scene["pose_to_camera"], scene["bone_length"], "center_fixed", scene["parents"])
+    cpose, cbl = O.register_canonical_pose(scene["canonical_pose"], scene["parents"], "center_fixed")
+    pts = torch.from_numpy(g["points"])
+    den, col, valid, taps = O.query(pts, O.scale_pose_translation(pose_p, 3.0), O.canonical_scale(cbl, bl_p, 3.0), cpose,
+                                    scene["tri_plane"], O.modulated_weights(scene["mlp"], scene["z_rend"]), return_taps=True,
+                                    multiply_density_with_weight=bool(g["mult_w"]), clamp_mask=bool(g["clamp_mask"]),
+                                    no_selector=bool(g["no_selector"]))
+    bits = (valid.numpy().astype(np.uint32) << np.arange(valid.shape[1], dtype=np.uint32)[None, :, None]).sum(axis=1).astype(np.uint32)
+    same = bits == g["valid"]
+    assert (~same).sum() <= 2
+    _assert_close(taps["weight"].numpy()[np.broadcast_to(same[:, None], taps["weight"].shape)],
+                  g["weight"][np.broadcast_to(same[:, None], g["weight"].shape)], "part weight")
+    _assert_close(den.numpy()[:, 0][same], g["density"][:, 0][same], "density")
+    _assert_close(col.numpy().transpose(0, 2, 1)[same], g["color"].transpose(0, 2, 1)[same], "colour")
+
+
 RENDER_CASES = ["render_c0_64_b1", "render_c1_128_b1_p23", "render_c1_128_b1_p24", "render_gan_32_b2",
                 "render_c4s_32_b2"]       # the last one: BASELINE config C4's sample counts, Nc 72 / Nf 96 (> 64)
 
