@@ -65,17 +65,31 @@ def density_volume(model, pose_to_camera: torch.Tensor, center: torch.Tensor, vo
 
 
 def create_mesh(model, pose_to_camera, center, voxel_size=0.003, mesh_th=15, model_input={}):
-    """mesh_rendering.py:50-81: density sweep + marching cubes -> (vertices, triangles, textures)."""
-    density = density_volume(model, pose_to_camera, center, voxel_size, model_input)
+    """mesh_rendering.py:50-81: density sweep + marching cubes -> (vertices, triangles, textures). The third-party
+    imports come first, as in the reference (:52 and the module imports), so a missing PyMCubes / pytorch3d fails
+    before any GPU work; `density_volume` is the sweep on its own."""
     try:
         import mcubes
         from pytorch3d.renderer import Textures
     except ImportError as e:      # same third-party requirements as the reference
         raise ImportError("create_mesh needs PyMCubes and pytorch3d (as the reference does); the density grid itself "
                           "is available from density_volume()") from e
+    density = density_volume(model, pose_to_camera, center, voxel_size, model_input)
     cube = int(1 / voxel_size)
     dev = pose_to_camera.device
     vertices, triangles = mcubes.marching_cubes(density.cpu().numpy(), mesh_th)
     vertices = torch.tensor((vertices - cube) * voxel_size, device=dev).float() + center[:, :, 0]
     triangles = torch.tensor(triangles.astype("int64")).to(dev)
     return vertices, triangles, Textures(verts_rgb=torch.ones_like(vertices)[None])
+
+
+def render_mesh_(meshes, intrinsics, img_size, render_size=512):
+    """mesh_rendering.py:17-47: Phong-shaded rasterisation of (vertices, triangles, textures) with pytorch3d. The
+    rasteriser is third-party and outside the hot path (out of scope); this raises ImportError where the
+    reference's module import would."""
+    try:
+        import pytorch3d.renderer  # noqa: F401
+    except ImportError as e:
+        raise ImportError("render_mesh_ needs pytorch3d (as the reference does)") from e
+    raise NotImplementedError("the pytorch3d rasteriser call is not rebuilt here (SURVEY.md §8, out of scope); "
+                              "use create_mesh() / density_volume() and rasterise with pytorch3d directly")

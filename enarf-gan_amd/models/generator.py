@@ -95,6 +95,28 @@ class TriNARFGenerator(_RendererShell):
         return image, alpha, side["fine_weights"], side["fine_depth"]
 
 
+    def render_mesh(self, pose_to_camera, intrinsics, z, bone_length, voxel_size=0.003, mesh_th=15, truncation_psi=0.4):
+        """models/generator.py:120-129."""
+        z_nerf, z_render, _ = self._latent_parts(z)
+        return self.nerf.render_mesh(pose_to_camera, intrinsics, z_nerf, z_render, bone_length, voxel_size, mesh_th,
+                                     truncation_psi, self.size)
+
+    def create_mesh(self, pose_to_camera, z, bone_length, voxel_size=0.003, mesh_th=15, truncation_psi=0.4):
+        """models/generator.py:131-140 (whose call passes arguments `create_mesh` does not take and cannot run as
+        written): the same sweep as render_mesh, returning (vertices, triangles, textures)."""
+        from ..libraries.NARF.mesh_rendering import create_mesh
+        z_nerf, z_render, _ = self._latent_parts(z)
+        center, pose_parts, model_input = self.nerf._mesh_inputs(pose_to_camera, z_nerf, z_render, bone_length,
+                                                                 truncation_psi)
+        return create_mesh(self.nerf, pose_parts, center=center, voxel_size=voxel_size, mesh_th=mesh_th,
+                           model_input=model_input)
+
+    def density_volume(self, pose_to_camera, z, bone_length, voxel_size=0.003, truncation_psi=0.4):
+        """The density grid behind render_mesh / create_mesh, without the third-party marching cubes."""
+        z_nerf, z_render, _ = self._latent_parts(z)
+        return self.nerf.density_volume(pose_to_camera, z_nerf, z_render, bone_length, voxel_size, truncation_psi)
+
+
 class DSONARFGenerator(_RendererShell):
     def __init__(self, config, size, num_bone=1, parent_id=None, num_bone_param=None):
         if not config.use_triplane:

@@ -295,6 +295,33 @@ class TriPlaneNARF(nn.Module):
         return render_entire_img(self, pose_parts, inv_intrinsics, camera_pose, render_size, Nc, Nf, semantic_map,
                                  use_normalized_intrinsics, no_grad, model_input, bbox=bbox)
 
+    def density_volume(self, pose_to_camera, z, z_rend, bone_length, voxel_size=0.003, truncation_psi=0.4):
+        """The (2/voxel_size + 1)^3 density grid `render_mesh` thresholds (libraries/NARF/base.py:65-77 up to the
+        marching-cubes call): one lattice-mode launch of the query kernel, the volume stays on the device."""
+        from ..libraries.NARF.mesh_rendering import density_volume
+        center, pose_parts, model_input = self._mesh_inputs(pose_to_camera, z, z_rend, bone_length, truncation_psi)
+        return density_volume(self, pose_parts, center, voxel_size, model_input)
+
+    def _mesh_inputs(self, pose_to_camera, z, z_rend, bone_length, truncation_psi):
+        if not ((z is None or z.shape[0] == 1) and (bone_length is None or bone_length.shape[0] == 1)):
+            raise AssertionError("render_mesh takes one sample (base.py:67-68)")
+        center = pose_to_camera[:, 0, :3, 3:].clone()  # (1, 3, 1)
+        model_input = {"z": z, "z_rend": z_rend, "bone_length": bone_length, "truncation_psi": truncation_psi}
+        pose_parts, model_input["bone_length"] = self.transform_pose(pose_to_camera, bone_length)
+        model_input["tri_plane_feature"] = self.compute_tri_plane_feature(z, bone_length)
+        return center, pose_parts, model_input
+
+    def render_mesh(self, pose_to_camera, intrinsics, z, z_rend, bone_length, voxel_size=0.003, mesh_th=15,
+                    truncation_psi=0.4, img_size=128):
+        """NARFBase.render_mesh (libraries/NARF/base.py:65-83): density sweep (HIP, lattice mode) -> marching cubes
+        (PyMCubes) -> Phong render (pytorch3d). The two third-party stages raise ImportError when absent, exactly where
+        the reference's imports would; `density_volume()` returns the swept grid without them."""
+        from ..libraries.NARF.mesh_rendering import create_mesh, render_mesh_
+        center, pose_parts, model_input = self._mesh_inputs(pose_to_camera, z, z_rend, bone_length, truncation_psi)
+        meshes = create_mesh(self, pose_parts, center=center, voxel_size=voxel_size, mesh_th=mesh_th,
+                             model_input=model_input)
+        return render_mesh_(meshes, intrinsics, img_size), meshes
+
     def calc_density_and_color_from_camera_coord_v2(self, position: torch.Tensor, pose_to_camera: torch.Tensor,
                                                     ray_direction: Optional[torch.Tensor], model_input: Dict):
         """models/narf.py:176-211: position (B,3,n) camera coords, pose_to_camera (B,P,4,4) part frames whose

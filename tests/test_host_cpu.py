@@ -177,6 +177,21 @@ def test_model_mirror_keeps_reference_names_and_state_dict_keys():
     assert gan.nerf.mlp.layers[0].conv.modulation.weight.shape == (32, 256)
 
 
+def test_mesh_api_fails_like_the_reference_without_its_third_party_stages():
+    """render_mesh / create_mesh (libraries/NARF/base.py:65-83, mesh_rendering.py:17-81) need PyMCubes and pytorch3d as
+    the reference does: with neither installed they raise ImportError before any device work."""
+    from enarf_gan_amd.libraries.NARF.mesh_rendering import create_mesh, render_mesh_
+    from enarf_gan_amd.models.generator import TriNARFGenerator
+    from enarf_gan_amd.models.narf import TriPlaneNARF
+    for name in ("render_mesh", "density_volume"):
+        assert callable(getattr(TriPlaneNARF, name)) and callable(getattr(TriNARFGenerator, name))
+    assert callable(TriNARFGenerator.create_mesh)
+    with pytest.raises(ImportError):
+        create_mesh(None, torch.zeros(1, 24, 4, 4), torch.zeros(1, 3, 1))
+    with pytest.raises(ImportError):
+        render_mesh_((None, None, None), torch.eye(3), 128)
+
+
 def test_ray_samplers_match_reference_formulas():
     from enarf_gan_amd import synth
     from enarf_gan_amd.libraries.NeRF.ray_sampler import mask_based_sampler, whole_image_grid_ray_sampler
