@@ -10,6 +10,9 @@
 #pragma once
 #include "enarf_device.h"
 
+#ifndef ENARF_ROUND_SWPIPE
+#define ENARF_ROUND_SWPIPE 1   // address generation of the next gather round under the loads of the current one
+#endif
 #ifndef ENARF_ROUND_PRIO
 #define ENARF_ROUND_PRIO 2
 #endif
@@ -615,6 +618,91 @@ __device__ __forceinline__ void query_tile(const QueryCtx &S, const int *cand_li
     // candidate tests too, or the MLP instead, gains less)
     __builtin_amdgcn_s_setprio(ENARF_ROUND_PRIO);
 #endif
+#if ENARF_ROUND_SWPIPE && !ENARF_DIAG_TAPCHECK && ENARF_TIMERS != 2
+    // Software-pipelined rounds: the address generation of round r + 1 (next part of every point, bone transform, the
+    // lane's own plane taps: ~120 VALU instructions that need only LDS and registers) runs while the last 8 loads of
+    // round r (plane zx) are in flight - the point of the round with the fewest live registers - instead of in front
+    // of its own loads. Same arithmetic on the same operands as the plain loop below: bit-identical results.
+    uint64_t bal = __ballot(rem != 0);
+    bool act = false;
+    int k = 0;
+    Taps t;
+    auto round_addr = [&](bool &a_act, int &a_k, Taps &a_t) {
+        a_act = rem != 0;
+        a_k = a_act ? __builtin_ctz(rem) : 0;
+        rem &= rem - 1;
+        float F[13], Cn[12], lx, ly, lz, cx, cy, cz;
+        load_frames(S, a_k, F, Cn);
+        exact_local(F, px, py, pz, lx, ly, lz);
+        exact_canonical(Cn, F[12], lx, ly, lz, cx, cy, cz);
+        const float qx = (g == 1) ? cy : (g == 2) ? cz : cx;     // lane g owns plane g: xy, yz, zx (lane 3 repeats plane 0)
+        const float qy = (g == 1) ? cz : (g == 2) ? cx : cy;
+#if ENARF_DIAG_GENERAL_TAPS
+        a_t = make_taps(qx, qy, S.H, S.W);
+#else
+        a_t = make_taps_valid(qx, qy, S.H, S.W);
+#endif
+    };
+    if (bal != 0) round_addr(act, k, t);
+    while (bal != 0) {
+        const bool act_c = act;
+        const int k_c = k;
+        const uint64_t bal_c = bal;
+        float acc[8], w = 0.0f;
+        TapRegs r0, r1, r2;
+        Taps t1, t2;
+        if (act_c) {   // quad-uniform, so the quad broadcasts see all four lanes
+            const int gm = (g == 3) ? 0 : g;
+            const char *maskb = reinterpret_cast<const char *>(S.mask);
+            const unsigned moff = ((unsigned)(3 * k_c + gm) * (unsigned)mplane) << 2;
+            const float m00 = *reinterpret_cast<const float *>(maskb + (moff + ((unsigned)t.o00 << 2)));
+            const float m01 = *reinterpret_cast<const float *>(maskb + (moff + ((unsigned)t.o01 << 2)));
+            const float m10 = *reinterpret_cast<const float *>(maskb + (moff + ((unsigned)t.o10 << 2)));
+            const float m11 = *reinterpret_cast<const float *>(maskb + (moff + ((unsigned)t.o11 << 2)));
+            const Taps t0 = quad_bcast_taps<0>(t);
+            t1 = quad_bcast_taps<1>(t);
+            tap4u_issue(featb, goff, t0, r0);
+            tap4u_issue(featb, goff + fplane_b, t1, r1);
+            __builtin_amdgcn_sched_barrier(0);
+            float macc = m00 * t.w00;   // part probability plane g (sampling.py:43-48, :62)
+            macc += m01 * t.w01;
+            macc += m10 * t.w10;
+            macc += m11 * t.w11;
+            if (S.clamp_mask) macc = fminf(fmaxf(macc, -2.0f), 5.0f);
+            const float sg = sigmoidf_(macc);
+            const float wp = (quad_bcast_f<0>(sg) * quad_bcast_f<1>(sg)) * quad_bcast_f<2>(sg);
+            w = (S.uniform_w > 0.0f) ? S.uniform_w : wp;
+            tap4u_reduce(r0, t0, acc);
+            pin8(acc);      // keep the reduction here: IR-level sinking would otherwise hold all 24 loads' registers
+            __builtin_amdgcn_sched_barrier(0);
+            t2 = quad_bcast_taps<2>(t);
+            tap4u_issue(featb, goff + 2u * fplane_b, t2, r2);
+            __builtin_amdgcn_sched_barrier(0);
+            float s1[8];
+            tap4u_reduce(r1, t1, s1);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc[c] += s1[c];
+            pin8(acc);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        bal = __ballot(rem != 0);
+        if (bal != 0) round_addr(act, k, t);        // next round's addresses, while plane zx's loads are in flight
+        __builtin_amdgcn_sched_barrier(0);
+        if (act_c) {
+            float s2[8];
+            tap4u_reduce(r2, t2, s2);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc[c] += s2[c];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) feat[c] += acc[c] * w;
+            wmax = fmaxf(wmax, w);
+            if (DBG && dbg.weight && g == 0) dbg.weight[(size_t)k_c * dbg.N + dbg.i] = w;
+        }
+        n_pairs += (unsigned)(__popcll(bal_c) >> 2);
+        if (n_rounds) *n_rounds += 1;
+        TMR(S, 3);
+    }
+#else
     while (true) {
         const uint64_t bal = __ballot(rem != 0);
         if (bal == 0) break;
@@ -715,6 +803,7 @@ __device__ __forceinline__ void query_tile(const QueryCtx &S, const int *cand_li
         TMR(S, 3);
     }
 
+#endif
 #if ENARF_ROUND_PRIO
     __builtin_amdgcn_s_setprio(0);
 #endif

@@ -192,12 +192,27 @@ def test_c4_256_nc72_nf96_bf16_early_termination():
 
 
 # ------------------------------------------------------------------------------------ range of the split-fp16 MLP arithmetic
+def _to_f64(x):
+    if torch.is_tensor(x):
+        return x.double() if x.is_floating_point() else x
+    if isinstance(x, dict):
+        return {k: _to_f64(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return type(x)(_to_f64(v) for v in x)
+    return x
+
+
 @pytest.mark.parametrize("scale", [1e-4, 1e-2, 1.0, 1e2, 1e4])
 def test_mlp_arithmetic_modes_over_feature_scales(scale):
-    """`f16x3` (the default: 3-term split fp16 on MFMA) and `f32` against the oracle in fp32 with the FEATURE planes scaled
-    by 1e-4 ... 1e+4 (the conv weights are row-normalised by the demodulation, custom_stylegan2/net.py:236-243, so their
-    scale cancels; the feature magnitude is what reaches the MLP). Operands of the split saturate at 65504 per half
-    (|x| < 1.3e5 stays exact) and the low half goes subnormal below |x| ~ 1e-4, where the absolute error is < 1e-7."""
+    """`f16x3` (the default: 3-term split fp16 on MFMA) and `f32` with the FEATURE planes scaled by 1e-4 ... 1e+4 (the conv
+    weights are row-normalised by the demodulation, custom_stylegan2/net.py:236-243, so their scale cancels; the feature
+    magnitude is what reaches the MLP). Operands of the split saturate at 65504 per half (|x| < 1.3e5 stays exact) and
+    the low half goes subnormal below |x| ~ 1e-4, where the absolute error is < 1e-7.
+
+    Bound: 1e-4 against the fp32 oracle while fp32 itself is that well conditioned. At feature magnitudes of 1e2 and more
+    it is not - the oracle in fp32 moves by 1e-3 ... 7e-3 against the same oracle in fp64 on a few tenths of a per cent of
+    the colours (cancellation in the hidden layers) - so there both modes are held to the fp64 result with the error the
+    reference's own fp32 arithmetic shows against it (x3, and twice its share of elements above 1e-4)."""
     sc = Scene(64, 1, "center_fixed", 20)
     sc.raw["tri_plane"] = sc.raw["tri_plane"].clone()
     sc.raw["tri_plane"][:, :96] *= scale
@@ -209,16 +224,27 @@ def test_mlp_arithmetic_modes_over_feature_scales(scale):
     from oracle import enarf_oracle as O
     oden, ocol, ovalid, taps = O.query(pts, sc.pose_scaled, sc.scale, sc.cpose, sc.raw["tri_plane"], sc.weights(), return_taps=True)
     assert int(ovalid.any(dim=1).sum()) > 1000
+    tden, tcol, tvalid = O.query(pts.double(), sc.pose_scaled.double(), sc.scale.double(), sc.cpose.double(),
+                                 sc.raw["tri_plane"].double(), _to_f64(sc.weights()))
+    assert torch.equal(tvalid, ovalid)
+    ref_err = {"density": rel_err(oden, tden), "colour": rel_err(ocol, tcol)}
     feat_max = float(taps["feature"].abs().max())
     for mode in ("f32", "f16x3"):
         den, col = ds.query(pts, mlp_mode=mode)
-        assert_close(_cpu(den), oden, f"density, features x {scale:g} (|feature| up to {feat_max:.3g}) [{mode}]")
-        assert_close(_cpu(col), ocol, f"colour, features x {scale:g} [{mode}]")
-    # and through the march: same bound on the image
+        for name, ours, o32, t64 in (("density", den, oden, tden), ("colour", col, ocol, tcol)):
+            what = f"{name}, features x {scale:g} (|feature| up to {feat_max:.3g}) [{mode}]"
+            if ref_err[name].max() < 5e-5:                      # fp32 well conditioned: the parity bound proper
+                assert_close(_cpu(ours), o32, what)
+            else:
+                e = rel_err(_cpu(ours), t64)
+                assert e.max() <= 3 * ref_err[name].max(), (what, e.max(), ref_err[name].max())
+                assert (e > 1e-4).mean() <= 2 * (ref_err[name] > 1e-4).mean() + 1e-4, what
+    # and through the march: the bound on the image (fp32's own conditioning, measured above, where it is worse)
+    tol = max(1e-4, 3 * float(ref_err["colour"].max()))
     coord = sc.raw["image_coord"][..., 64 * 28:64 * 28 + 128].contiguous()
     bins = torch.rand(1, 128, 32, generator=g).sort(-1).values
     rc, rm, rd = sc.oracle_render(coord, 48, 32, bins, taps=False)
     for mode in ("f32", "f16x3"):
         out = ds.render(coord, 48, 32, bins, mlp_mode=mode)
         assert_close(_cpu(out.mask), rm, f"mask, features x {scale:g} [{mode}]")
-        assert_close(_cpu(out.color), rc, f"colour, features x {scale:g} [{mode}]")
+        assert_close(_cpu(out.color), rc, f"colour, features x {scale:g} [{mode}]", tol)

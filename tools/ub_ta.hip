@@ -4,6 +4,9 @@
 // exactly one gather round of enarf_query.h - from a 25 MB channel-last table (one image's feature planes), with `active`
 // of the wave's 16 quads enabled. pattern 0: 12 independent random texels; pattern 1: 3 random 2x2 bilinear footprints
 // (taps x, x+1 adjacent 128-B lines; y, y+1 one row apart), consecutive quads a few texels apart like samples along a ray.
+// pattern 2: as 1, but a lane's two 16-B loads are 64 B apart (each instruction covers a contiguous 64 B per quad) instead
+// of adjacent; pattern 3: as 1 plus the 4 scalar (dword) part-probability taps of a round; pattern 4: as 1 with half-size
+// texels (64 B, one 16-B load per lane and texel - what fp16 feature planes would cost).
 // 768 workgroups x 4 waves (3 waves per SIMD, as the march runs). Build: hipcc --offload-arch=gfx950 -O3 tools/ub_ta.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -18,7 +21,8 @@ __global__ __launch_bounds__(256, 3) void gather(const float *__restrict__ tab, 
     const bool on = quad < active_quads;
     for (int r = 0; r < rounds; ++r) {
         unsigned tex[12];
-        if (PATTERN == 0) {
+        constexpr int FOOT = PATTERN == 0 ? 0 : 1;
+        if (FOOT == 0) {
             unsigned q = s + quad * 97u;
 #pragma unroll
             for (int t = 0; t < 12; ++t) { q = q * 1664525u + 1013904223u; tex[t] = (q >> 8) % (3 * PLANE); }
@@ -35,9 +39,21 @@ __global__ __launch_bounds__(256, 3) void gather(const float *__restrict__ tab, 
         if (on) {
 #pragma unroll
             for (int t = 0; t < 12; ++t) {
-                const f32x4 *p = reinterpret_cast<const f32x4 *>(tab + (size_t)tex[t] * 32 + g * 8);
-                acc += p[0];
-                acc += p[1];
+                if (PATTERN == 2) {
+                    const f32x4 *p = reinterpret_cast<const f32x4 *>(tab + (size_t)tex[t] * 32 + g * 4);
+                    acc += p[0];
+                    acc += p[4];
+                } else if (PATTERN == 4) {
+                    acc += *reinterpret_cast<const f32x4 *>(tab + (size_t)tex[t] * 16 + g * 4);
+                } else {
+                    const f32x4 *p = reinterpret_cast<const f32x4 *>(tab + (size_t)tex[t] * 32 + g * 8);
+                    acc += p[0];
+                    acc += p[1];
+                }
+            }
+            if (PATTERN == 3) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[0] += tab[(size_t)((tex[4 * (g % 3) + t] * 7u) % (3 * PLANE)) * 32 + 5];
             }
         }
     }
@@ -52,20 +68,26 @@ int main() {
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     const int rounds = 250, wgs = 768;
-    for (int pattern = 0; pattern < 2; ++pattern)
+    for (int pattern = 0; pattern < 5; ++pattern)
         for (int active : {16, 12, 8, 4}) {
+            if (pattern >= 2 && active != 16 && active != 12) continue;
             float best = 1e9f;
             for (int rep = 0; rep < 4; ++rep) {
                 (void)hipEventRecord(e0);
-                if (pattern == 0) hipLaunchKernelGGL(gather<0>, dim3(wgs), dim3(256), 0, 0, tab, out, rounds, active);
-                else hipLaunchKernelGGL(gather<1>, dim3(wgs), dim3(256), 0, 0, tab, out, rounds, active);
+                switch (pattern) {
+                case 0: hipLaunchKernelGGL(gather<0>, dim3(wgs), dim3(256), 0, 0, tab, out, rounds, active); break;
+                case 1: hipLaunchKernelGGL(gather<1>, dim3(wgs), dim3(256), 0, 0, tab, out, rounds, active); break;
+                case 2: hipLaunchKernelGGL(gather<2>, dim3(wgs), dim3(256), 0, 0, tab, out, rounds, active); break;
+                case 3: hipLaunchKernelGGL(gather<3>, dim3(wgs), dim3(256), 0, 0, tab, out, rounds, active); break;
+                default: hipLaunchKernelGGL(gather<4>, dim3(wgs), dim3(256), 0, 0, tab, out, rounds, active); break;
+                }
                 (void)hipEventRecord(e1);
                 (void)hipEventSynchronize(e1);
                 float ms;
                 (void)hipEventElapsedTime(&ms, e0, e1);
                 if (rep && ms < best) best = ms;
             }
-            const double b = (double)wgs * 4 * rounds * active * 12 * 128;
+            const double b = (double)wgs * 4 * rounds * active * 12 * (pattern == 4 ? 64 : 128);
             printf("pattern %d active quads %2d/16: %.3f ms  %.2f TB/s gathered  %.0f ns per wave-round (%d rounds)\n", pattern, active,
                    best, b / best / 1e9, best * 1e6 / rounds, rounds);
         }
