@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--nf", type=int, default=64)
     ap.add_argument("--origin", default="center_fixed", choices=["center", "center_fixed", "center+head"])
     ap.add_argument("--mlp-mode", default="f16x3", choices=["f32", "f16x3", "bf16x3", "bf16"])
+    ap.add_argument("--march", default="auto", choices=["auto", "ray", "task"],
+                    help="which march kernel (ENARF_MARCH_*): auto picks by shape; both give the same bits")
     ap.add_argument("--style-dim", type=int, default=20)
     ap.add_argument("--early-stop-eps", type=float, default=0.0, help="opt-in early ray termination (0 = exact)")
     ap.add_argument("--cache-triplane", action="store_true", help="re-lay the (constant) tri-plane once instead of every step")
@@ -204,13 +206,14 @@ def main():
         return ops.RenderStep(d["pose_to_camera"], d["bone_length"], cbl_d, d["z_rend"], mlp, sc["parents"], args.origin,
                               3.0, coord, d["inv_intrinsics"], cpose_d, tri, f, Nc, Nf, parts_out=pa,
                               pack_out=pk, relayout=not args.cache_triplane, seed=seed, mlp_mode=mode or args.mlp_mode,
-                              want_fine=True, count=count, early_stop_eps=args.early_stop_eps, return_bins=return_bins)
+                              want_fine=True, count=count, early_stop_eps=args.early_stop_eps, return_bins=return_bins,
+                              march=args.march)
 
     # ---- the training step (opt-in): forward + backward + gradient all-reduce of the renderer's parameters
     train_params = None
     if args.train_step:
-        if Nf > 64:
-            raise SystemExit("--train-step: the backward handles Nf <= 64")
+        if Nf > 128:
+            raise SystemExit("--train-step: the backward handles Nf <= 128")
         tri_param = torch.nn.Parameter(tri.clone())
         mlp_params = {k: torch.nn.Parameter(v.clone()) for k, v in mlp.items() if "noise" not in k}
         train_params = [tri_param] + [mlp_params[k] for k in sorted(mlp_params)]
@@ -404,7 +407,7 @@ def main():
                        "sharding": ("rays of one frame batch across ranks + all-gather of outputs" if shard else
                                     f"a fixed batch of {world * B} frames dealt {B} per rank" if multi else "one frame batch per rank"),
                        "library": _lib.library_info(), "env": {k: v for k, v in os.environ.items() if k.startswith("ENARF_")},
-                       "spinup_ms": args.spinup_ms, "streams": n_streams, "mlp_arith": args.mlp_mode,
+                       "spinup_ms": args.spinup_ms, "streams": n_streams, "mlp_arith": args.mlp_mode, "march": args.march,
                        "early_stop_eps": args.early_stop_eps, "triplane_relayout_in_step": not args.cache_triplane,
                        "step": step_desc},
             "roofline": roof,

@@ -37,6 +37,7 @@ INTERP = {"bilinear": 0, "nearest": 1}            # cuda_extension/triplane_samp
 PADDING = {"zeros": 0, "border": 1, "reflection": 2}   # :12-16
 ORIGIN = {"center": 0, "center_fixed": 1, "center+head": 2}
 MLP_MODE = {"f32": 0, "bf16x3": 1, "bf16": 2, "f16x3": 3}
+MARCH = {"auto": 0, "ray": 1, "task": 2}          # ENARF_MARCH_* (include/enarf_hip.h)
 
 _f32p = C.c_void_p   # device pointers travel as integers
 
@@ -78,7 +79,7 @@ class RenderArgs(C.Structure):
         ("dbg_depth_min", _f32p), ("dbg_depth_max", _f32p), ("dbg_ray_valid", _f32p),
         ("dbg_coarse_density", _f32p), ("dbg_fine_density", _f32p), ("dbg_fine_color", _f32p),
         ("dbg_fine_valid", _f32p), ("dbg_bins", _f32p), ("counters", _f32p), ("workspace", _f32p),
-        ("clamp_mask", C.c_int), ("uniform_part_weight", C.c_int), ("ws_epoch", C.c_int),
+        ("clamp_mask", C.c_int), ("uniform_part_weight", C.c_int), ("march", C.c_int), ("ws_epoch", C.c_int),
     ]
 
 

@@ -217,6 +217,8 @@ __device__ __forceinline__ float exact_dot3(float a0, float b0, float a1, float 
 struct Taps {
     int o00, o01, o10, o11;        // y*W + x of nw, ne, sw, se (clamped in-bounds)
     float w00, w01, w10, w11;      // weights, zeroed for out-of-bounds taps
+    int xe;                        // x edge: 0 = x0, x0 + 1 both in the plane; 1 = x0 left of it (o00 == o01, column 0);
+                                   // 2 = x1 right of it (o00 == o01, column W - 1). Only meaningful for x0 in [-1, W - 1].
 };
 __host__ __device__ __forceinline__ Taps make_taps(float x, float y, int H, int W) {
     Taps t;
@@ -241,6 +243,7 @@ __host__ __device__ __forceinline__ Taps make_taps(float x, float y, int H, int 
     t.w01 = zx1 * zy0;
     t.w10 = zx0 * zy1;
     t.w11 = zx1 * zy1;
+    t.xe = (x0 < 0) ? 1 : (x1 >= W) ? 2 : 0;
     return t;
 }
 // The same taps for coordinates of a VALID (part, point) pair, i.e. |x| < 1 and |y| < 1 strictly (narf.py:201), with half
@@ -275,7 +278,20 @@ __host__ __device__ __forceinline__ Taps make_taps_valid(float x, float y, int H
     t.w01 = zx1 * zy0;
     t.w10 = zx0 * zy1;
     t.w11 = zx1 * zy1;
+    t.xe = (x0 < 0) ? 1 : (x1 >= W) ? 2 : 0;
     return t;
+}
+// The two taps of one row of a scalar (fp32, row-major) plane with ONE 8-byte load: x0 and x0 + 1 are adjacent floats.
+// At the left edge both taps are column 0 (pair = columns 0, 1: both taps take .x), at the right edge both are column
+// W - 1 (pair = columns W - 2, W - 1: both take .y; the pair must not start at W - 1, the float behind the last row of
+// the last plane is not ours). The address is only 4-byte aligned: gfx950 under HSA runs with unaligned access enabled.
+typedef float f32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+__device__ __forceinline__ void load_row_pair(const char *__restrict__ plane_bytes, unsigned plane_off, int o_left, int xe,
+                                              float &left, float &right) {
+    const unsigned e = (unsigned)(o_left - (xe == 2 ? 1 : 0));
+    const f32x2_a4 v = *reinterpret_cast<const f32x2_a4 *>(plane_bytes + (plane_off + (e << 2)));
+    left = (xe == 2) ? v.y : v.x;
+    right = (xe == 1) ? v.x : v.y;
 }
 __device__ __forceinline__ float sample_scalar_plane(const float *__restrict__ plane, float x, float y,
                                                      int H, int W) {

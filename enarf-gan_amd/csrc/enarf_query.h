@@ -10,8 +10,11 @@
 #pragma once
 #include "enarf_device.h"
 
-#ifndef ENARF_ROUND_SWPIPE
-#define ENARF_ROUND_SWPIPE 1   // address generation of the next gather round under the loads of the current one
+#ifndef ENARF_ROUND_SWPIPE     // A/B only: address generation of the next gather round under the last loads of the current
+#define ENARF_ROUND_SWPIPE 0   // one. Measured SLOWER (C1 march 0.235 -> 0.270 ms, both march kernels): DESIGN.md 3.1
+#endif
+#ifndef ENARF_MASK_ROW_PAIRS   // the 4 part-probability taps of a round as 2 eight-byte loads (x0, x0 + 1 are adjacent floats)
+#define ENARF_MASK_ROW_PAIRS 1
 #endif
 #ifndef ENARF_ROUND_PRIO
 #define ENARF_ROUND_PRIO 2
@@ -478,48 +481,94 @@ __device__ __forceinline__ void mfma_acc1x2(f32x4 &o, const short *__restrict__ 
     }
 }
 
-template <bool F16, int NTERMS>
-__device__ __forceinline__ f32x4 mlp_tile_split(const float *__restrict__ Bp, const short *__restrict__ Hp, const float x[8],
-                                                int lane) {
+// `peak` (F16 only) returns the largest operand magnitude this lane fed into a split: features, then the two hidden
+// activations. The fp16 halves carry 22 bits only while |operand| <= 65504 (above, `hi` saturates and `lo` alone cannot
+// hold the rest). SCALED evaluates the same network on x * s with every bias * s: bias-add, LeakyReLU * sqrt(2) and the
+// products are positively homogeneous, so every intermediate is the unscaled one times s - exactly, for s a power of two -
+// and the caller divides the result by s (mlp_tile below).
+template <bool F16, int NTERMS, bool SCALED>
+__device__ __forceinline__ f32x4 mlp_tile_split(const float *__restrict__ Bp, const short *__restrict__ Hp, const float xin[8],
+                                                int lane, float s, float &peak) {
     const int g = lane >> 4;
     f32x4 a1[4], a2[4];
     i32x4 bh, bl;
+    float m = 0.0f, x[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = SCALED ? xin[i] * s : xin[i];
+    if (F16 && !SCALED) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) m = fmaxf(m, fabsf(x[i]));
+    }
     if (F16) split8h(x, bh, bl); else split8(x, bh, bl);
 #pragma unroll
-    for (int ob = 0; ob < 4; ++ob) a1[ob] = *reinterpret_cast<const f32x4 *>(Bp + 16 * ob + 4 * g);
+    for (int ob = 0; ob < 4; ++ob) {
+        a1[ob] = *reinterpret_cast<const f32x4 *>(Bp + 16 * ob + 4 * g);
+        if (SCALED) a1[ob] *= s;
+    }
     mfma_acc4<F16, NTERMS>(a1, Hp + PKH_W1, 1024, bh, bl, lane);
 #pragma unroll
     for (int ob = 0; ob < 4; ++ob) {
         a1[ob] = act4(a1[ob]);
         a2[ob] = *reinterpret_cast<const f32x4 *>(Bp + 64 + 16 * ob + 4 * g);
+        if (SCALED) a2[ob] *= s;
     }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
         float v[8];
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) v[jj] = a1[2 * ks + (jj >> 2)][jj & 3];
+        if (F16 && !SCALED) {
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) m = fmaxf(m, fabsf(v[jj]));
+        }
         if (F16) split8h(v, bh, bl); else split8(v, bh, bl);
         mfma_acc4<F16, NTERMS>(a2, Hp + PKH_W2 + ks * 1024, 2048, bh, bl, lane);
     }
     f32x4 o = *reinterpret_cast<const f32x4 *>(Bp + 128 + 4 * g);
+    if (SCALED) o *= s;
     i32x4 ch[2], cl[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
         float v[8];
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) v[jj] = styled_act(a2[2 * ks + (jj >> 2)][jj & 3]);
+        if (F16 && !SCALED) {
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) m = fmaxf(m, fabsf(v[jj]));
+        }
         if (F16) split8h(v, ch[ks], cl[ks]); else split8(v, ch[ks], cl[ks]);
     }
     mfma_acc1x2<F16, NTERMS>(o, Hp + PKH_W3, ch[0], cl[0], ch[1], cl[1], lane);
+    peak = m;
     return act4(o);
 }
 
 template <int MODE>
 __device__ __forceinline__ f32x4 mlp_tile(const QueryCtx &S, const float x[8], int lane) {
-    if (MODE == ENARF_MLP_F16X3) return mlp_tile_split<true, 3>(S.bias, S.mlp_h, x, lane);
+    float peak = 0.0f;
+    if (MODE == ENARF_MLP_F16X3) {
+        f32x4 o = mlp_tile_split<true, 3, false>(S.bias, S.mlp_h, x, lane, 1.0f, peak);
+        // Range guard (tests/test_gpu_configs.py::test_mlp_arithmetic_modes_over_feature_scales): a tile in which any
+        // operand left the fp16 pair's range is evaluated again, scaled by the power of two that brings the wave's
+        // largest operand to [2^14, 2^15) - rare: trained features are O(1..10). A NaN operand does not trigger it and
+        // propagates as it does in fp32; an infinite one stays infinite.
+        if (__ballot(peak > 65504.0f) != 0) {
+            float pm = peak;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) pm = fmaxf(pm, __shfl_xor(pm, off));
+            if (pm < 3.0e38f) {
+                int e;
+                (void)frexpf(pm, &e);                                   // pm < 2^e
+                const float s = ldexpf(1.0f, 15 - e), inv = ldexpf(1.0f, e - 15);
+                float unused;
+                o = mlp_tile_split<true, 3, true>(S.bias, S.mlp_h, x, lane, s, unused) * inv;
+            }
+        }
+        return o;
+    }
     if (MODE == ENARF_MLP_F32) return mlp_tile_f32(S.mlp, S.bias, x, lane);
-    if (MODE == ENARF_MLP_BF16X3) return mlp_tile_split<false, 3>(S.bias, S.mlp_h, x, lane);
-    return mlp_tile_split<false, 1>(S.bias, S.mlp_h, x, lane);
+    if (MODE == ENARF_MLP_BF16X3) return mlp_tile_split<false, 3, false>(S.bias, S.mlp_h, x, lane, 1.0f, peak);
+    return mlp_tile_split<false, 1, false>(S.bias, S.mlp_h, x, lane, 1.0f, peak);
 }
 
 // ---- quad (4 adjacent lanes) primitives: DPP quad_perm, no LDS -----------------------------------------------
@@ -655,10 +704,18 @@ __device__ __forceinline__ void query_tile(const QueryCtx &S, const int *cand_li
             const int gm = (g == 3) ? 0 : g;
             const char *maskb = reinterpret_cast<const char *>(S.mask);
             const unsigned moff = ((unsigned)(3 * k_c + gm) * (unsigned)mplane) << 2;
+#if ENARF_MASK_ROW_PAIRS
+            // the four part-probability taps as two 8-byte row pairs: the texture path charges a load instruction by the
+            // cache lines it touches (48 here: 16 quads x 3 planes), not by its width - two instructions instead of four
+            float m00, m01, m10, m11;
+            load_row_pair(maskb, moff, t.o00, t.xe, m00, m01);
+            load_row_pair(maskb, moff, t.o10, t.xe, m10, m11);
+#else
             const float m00 = *reinterpret_cast<const float *>(maskb + (moff + ((unsigned)t.o00 << 2)));
             const float m01 = *reinterpret_cast<const float *>(maskb + (moff + ((unsigned)t.o01 << 2)));
             const float m10 = *reinterpret_cast<const float *>(maskb + (moff + ((unsigned)t.o10 << 2)));
             const float m11 = *reinterpret_cast<const float *>(maskb + (moff + ((unsigned)t.o11 << 2)));
+#endif
             const Taps t0 = quad_bcast_taps<0>(t);
             t1 = quad_bcast_taps<1>(t);
             tap4u_issue(featb, goff, t0, r0);
@@ -748,17 +805,25 @@ __device__ __forceinline__ void query_tile(const QueryCtx &S, const int *cand_li
             const int gm = (g == 3) ? 0 : g;   // lane 3 repeats plane 0 (same addresses as lane 0: no extra traffic)
             const char *maskb = reinterpret_cast<const char *>(S.mask);
             const unsigned moff = ((unsigned)(3 * k + gm) * (unsigned)mplane) << 2;
+#if ENARF_MASK_ROW_PAIRS
+            // the four part-probability taps as two 8-byte row pairs: the texture path charges a load instruction by the
+            // cache lines it touches (48 here: 16 quads x 3 planes), not by its width - two instructions instead of four
+            float m00, m01, m10, m11;
+            load_row_pair(maskb, moff, t.o00, t.xe, m00, m01);
+            load_row_pair(maskb, moff, t.o10, t.xe, m10, m11);
+#else
             const float m00 = *reinterpret_cast<const float *>(maskb + (moff + ((unsigned)t.o00 << 2)));
             const float m01 = *reinterpret_cast<const float *>(maskb + (moff + ((unsigned)t.o01 << 2)));
             const float m10 = *reinterpret_cast<const float *>(maskb + (moff + ((unsigned)t.o10 << 2)));
             const float m11 = *reinterpret_cast<const float *>(maskb + (moff + ((unsigned)t.o11 << 2)));
+#endif
             TapRegs r0, r1, r2;
             const Taps t0 = quad_bcast_taps<0>(t), t1 = quad_bcast_taps<1>(t);
             tap4u_issue(featb, goff, t0, r0);
             tap4u_issue(featb, goff + fplane_b, t1, r1);
             __builtin_amdgcn_sched_barrier(0);
             TMR2(S, 0);
-            TMR2_WAIT(S, 1, 0x4F70);     // vmcnt(16)
+            TMR2_WAIT(S, 1, 0x4F70);     // vmcnt(16)  (diagnostic build: meaningful with ENARF_MASK_ROW_PAIRS=0 only)
             float macc = m00 * t.w00;   // part probability plane g (sampling.py:43-48, :62)
             macc += m01 * t.w01;
             macc += m10 * t.w10;

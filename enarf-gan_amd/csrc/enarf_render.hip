@@ -1003,8 +1003,15 @@ int device_cus() {
 }
 }  // namespace enarf
 
-#ifndef ENARF_TASK_MARCH            // 1: the tile-task march (enarf_tasks.h); 0: the round-1 workgroup-per-ray march (A/B builds)
-#define ENARF_TASK_MARCH 1
+// Two march kernels share every stage (enarf_march.h, enarf_query.h, enarf_tasks.h) and produce the same bits:
+//   render_kernel   one workgroup (4 waves) marches one ray at a time, 3 workgroups per CU, three barriers per ray;
+//   march_kernel    one workgroup (12 waves) per CU, several rays in flight, 16-sample tiles claimed as tasks.
+// ENARF_TASK_MARCH: 0 / 1 force one of them (A/B builds); 2 (product) picks by shape, from measurements on MI355X
+// (DESIGN.md 3.1): the task march wins where a pass has more tiles than a 4-wave workgroup has waves (Nc or Nf > 64:
+// 0.32 vs 0.36 ms at 128^2, 72 + 96), ties at 48 + 64 (0.235 vs 0.229) and loses on batches, where every change of
+// image drains its pipeline (8 frames: 2.60 vs 1.82 ms).
+#ifndef ENARF_TASK_MARCH
+#define ENARF_TASK_MARCH 2
 #endif
 #ifndef ENARF_TASK_WAVES
 #define ENARF_TASK_WAVES 12
@@ -1043,8 +1050,11 @@ static int launch_task_march(const enarf_render_args &a, hipStream_t st, bool wi
 
 template <int MODE, int SPL>
 static int launch_render(const enarf_render_args &a, hipStream_t st, bool with_setup) {
-#if ENARF_TASK_MARCH
+#if ENARF_TASK_MARCH == 1
     return launch_task_march<MODE, SPL>(a, st, with_setup);
+#elif ENARF_TASK_MARCH == 2
+    if (a.march == ENARF_MARCH_TASK || (a.march == ENARF_MARCH_AUTO && SPL == 2 && a.B == 1))
+        return launch_task_march<MODE, SPL>(a, st, with_setup);
 #endif
     // persistent grid: as many workgroups as stay resident (3 per CU at <= 168 VGPRs and ~37 KB LDS), never more
     // than there are rays
@@ -1078,6 +1088,7 @@ static int check_render(const enarf_render_args &a) {
         return host::fail(ENARF_ERR_ARG, "enarf_render_fwd: dbg_depth_min needs dbg_depth_max and dbg_ray_valid");
     if ((long long)((a.n + 63) / 64) * a.B > 0x7FFFFFFFll || (long long)a.n * a.B > 0x7FFFFFF0ll) return host::fail(ENARF_ERR_UNSUPPORTED, "enarf_render_fwd: more than 2^31 rays in one launch");
     if (!a.workspace) return host::fail(ENARF_ERR_ARG, "enarf_render_fwd: workspace is null (enarf_render_workspace_bytes() bytes of device memory)");
+    if (a.march < ENARF_MARCH_AUTO || a.march > ENARF_MARCH_TASK) return host::fail(ENARF_ERR_ARG, "enarf_render_fwd: bad march %d (ENARF_MARCH_*)", a.march);
     return 0;
 }
 

@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import FEAT_DIM, MLP_MODE, ORIGIN
+from ._lib import FEAT_DIM, MARCH, MLP_MODE, ORIGIN
 
 PLANE_CH = 3 * FEAT_DIM   # 96 feature channels precede the part-probability planes (models/narf.py:239,255)
 
@@ -443,13 +443,13 @@ def render_fwd(image_coord: torch.Tensor, inv_intrinsics: torch.Tensor, parts: t
                mlp_mode: str = "f32", multiply_density_with_weight: bool = False,
                drop_invalid_rays: Optional[bool] = None, want_fine: bool = True, debug: bool = False,
                count: bool = False, early_stop_eps: float = 0.0, return_bins: bool = False, clamp_mask: bool = False,
-               uniform_part_weight: bool = False) -> RenderOutputs:
+               uniform_part_weight: bool = False, march: str = "auto") -> RenderOutputs:
     """The fused ray march. image_coord (B,1,3,n) or (B,3,n); returns color (B,3,n), mask (B,n), disparity (B,n),
     fine_weights (B,1,n,Nf-1), fine_depth (B,1,n,Nf) and, with debug=True, the parity taps."""
     lib = _lib.load()
     a, o, _keep = _render_args(image_coord, inv_intrinsics, parts, canonical_pose, tri_nchw, feat_cl, mlp_pack, Nc, Nf,
                                render_scale, bins, seed, mlp_mode, multiply_density_with_weight, drop_invalid_rays,
-                               want_fine, debug, count, early_stop_eps, return_bins, clamp_mask, uniform_part_weight)
+                               want_fine, debug, count, early_stop_eps, return_bins, clamp_mask, uniform_part_weight, march)
     with _Epoch(o.color.device) as k:
         a.ws_epoch = k
         _lib.check(lib.enarf_render_fwd(C.byref(a), _stream(o.color.device)), "enarf_render_fwd")
@@ -458,7 +458,7 @@ def render_fwd(image_coord: torch.Tensor, inv_intrinsics: torch.Tensor, parts: t
 
 def _render_args(image_coord, inv_intrinsics, parts, canonical_pose, tri_nchw, feat_cl, mlp_pack, Nc, Nf, render_scale,
                  bins, seed, mlp_mode, multiply_density_with_weight, drop_invalid_rays, want_fine, debug, count,
-                 early_stop_eps, return_bins, clamp_mask=False, uniform_part_weight=False):
+                 early_stop_eps, return_bins, clamp_mask=False, uniform_part_weight=False, march="auto"):
     """enarf_render_args with freshly allocated outputs + the tensors its pointers borrow."""
     coord = _dev_f32(image_coord, "image_coord")
     B, n = coord.shape[0], coord.shape[-1]
@@ -484,6 +484,7 @@ def _render_args(image_coord, inv_intrinsics, parts, canonical_pose, tri_nchw, f
     a.drop_invalid_rays = int(B == 1 if drop_invalid_rays is None else drop_invalid_rays)
     a.render_scale, a.early_stop_eps = float(render_scale), float(early_stop_eps)
     a.clamp_mask, a.uniform_part_weight = int(bool(clamp_mask)), int(bool(uniform_part_weight))
+    a.march = MARCH[march]
     a.image_coord, a.inv_intrinsics, a.parts = _p(coord), _p(Ki), _p(parts)
     cpose = _dev_f32(canonical_pose, "canonical_pose")
     a.canonical_pose = _p(cpose)
@@ -531,7 +532,7 @@ class RenderStep:
                  coordinate_scale, image_coord, inv_intrinsics, canonical_pose, tri_nchw, feat_cl, Nc, Nf,
                  parts_out=None, pack_out=None, relayout=True, render_scale=1.0, bins=None, seed=0, mlp_mode="f32",
                  multiply_density_with_weight=False, drop_invalid_rays=None, want_fine=True, debug=False, count=False,
-                 early_stop_eps=0.0, return_bins=False, clamp_mask=False, uniform_part_weight=False):
+                 early_stop_eps=0.0, return_bins=False, clamp_mask=False, uniform_part_weight=False, march="auto"):
         self.lib = _lib.load()
         self.pa, k1, self.parts, self.pack = _prepare_args(pose_to_camera, bone_length, canonical_bone_length, z_rend,
                                                            mlp, parents, origin_location, coordinate_scale, parts_out,
@@ -539,7 +540,7 @@ class RenderStep:
         self.ra, self.out, k2 = _render_args(image_coord, inv_intrinsics, self.parts, canonical_pose, tri_nchw, feat_cl,
                                              self.pack, Nc, Nf, render_scale, bins, seed, mlp_mode,
                                              multiply_density_with_weight, drop_invalid_rays, want_fine, debug, count,
-                                             early_stop_eps, return_bins, clamp_mask, uniform_part_weight)
+                                             early_stop_eps, return_bins, clamp_mask, uniform_part_weight, march)
         self.tri = _dev_f32(tri_nchw, "tri_plane")
         self.feat_cl, self.relayout = feat_cl, relayout
         if feat_cl.shape[0] != self.tri.shape[0]:

@@ -41,6 +41,10 @@ extern "C" {
 #define ENARF_ORIGIN_CENTER_HEAD  2
 
 /* arithmetic of the density/colour MLP (libraries/NeRF/net.py:10-27) */
+#define ENARF_MARCH_AUTO   0   /* by shape, from measurements (enarf_render.hip): the default */
+#define ENARF_MARCH_RAY    1   /* one 4-wave workgroup marches one ray at a time (3 workgroups per CU) */
+#define ENARF_MARCH_TASK   2   /* one 12-wave workgroup per CU, several rays in flight, 16-sample tiles claimed as tasks */
+
 #define ENARF_MLP_F32     0   /* v_mfma_f32_16x16x4_f32: exact fp32 products (bitwise an fmaf chain) */
 #define ENARF_MLP_BF16X3  1   /* 3-term split-bf16 on v_mfma_f32_16x16x32_bf16: ~1e-5 relative */
 #define ENARF_MLP_BF16    2   /* plain bf16 operands, fp32 accumulate: ~4e-3 relative */
@@ -233,6 +237,7 @@ typedef struct {
                                              records (depth range, candidate parts, direction) and the ray lists; one
                                              workspace must not be shared by launches that can overlap. */
     int clamp_mask, uniform_part_weight;  /* as in enarf_query_args */
+    int march;                            /* ENARF_MARCH_*: which of the two march kernels runs (same results, bit for bit) */
     int ws_epoch;                         /* 0: the call clears the queue headers itself (one extra fill launch on
                                              `stream`) - always safe. k > 0: the caller promises that the previous call
                                              that used this workspace had ws_epoch k - 1 (any of enarf_render_fwd /

@@ -59,6 +59,18 @@ int main() {
                         if (std::memcmp(&wg[i], &wt[i], 4) != 0) { std::printf("make_taps_valid(%.9g, %.9g): weight %d differs (%g vs %g)\n", x, y, i, wt[i], wg[i]); return 1; }
                         if (wg[i] != 0.0f && og[i] != ot[i]) { std::printf("make_taps_valid(%.9g, %.9g): offset %d differs (%d vs %d)\n", x, y, i, ot[i], og[i]); return 1; }
                     }
+                    // the row-pair form of the scalar taps (load_row_pair, enarf_device.h): the 8-byte pair starts inside the
+                    // row, ends inside the row, and its two selected elements are exactly the taps o00 / o01 (o10 / o11)
+                    for (const Taps &q : {g, t}) {
+                        if (q.xe != g.xe) { std::printf("xe differs at (%.9g, %.9g)\n", x, y); return 1; }
+                        const int rows[2][2] = {{q.o00, q.o01}, {q.o10, q.o11}};
+                        for (const auto &r : rows) {
+                            const int e = r[0] - (q.xe == 2 ? 1 : 0), row = r[0] / W;
+                            if (e < row * W || e + 1 > row * W + W - 1) { std::printf("row pair leaves the row at (%.9g, %.9g) W=%d: %d\n", x, y, W, e); return 1; }
+                            const int left = (q.xe == 2) ? e + 1 : e, right = (q.xe == 1) ? e : e + 1;
+                            if (left != r[0] || right != r[1]) { std::printf("row pair selects %d, %d for taps %d, %d at (%.9g, %.9g)\n", left, right, r[0], r[1], x, y); return 1; }
+                        }
+                    }
                     ++checked;
                 }
         // the case behind the round-1 fault: the last half texel before +1 has x1 == W (y1 == H)

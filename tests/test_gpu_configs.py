@@ -202,12 +202,15 @@ def _to_f64(x):
     return x
 
 
-@pytest.mark.parametrize("scale", [1e-4, 1e-2, 1.0, 1e2, 1e4])
+@pytest.mark.parametrize("scale", [1e-4, 1e-2, 1.0, 1e2, 1e4, 1e6])
 def test_mlp_arithmetic_modes_over_feature_scales(scale):
     """`f16x3` (the default: 3-term split fp16 on MFMA) and `f32` with the FEATURE planes scaled by 1e-4 ... 1e+4 (the conv
     weights are row-normalised by the demodulation, custom_stylegan2/net.py:236-243, so their scale cancels; the feature
-    magnitude is what reaches the MLP). Operands of the split saturate at 65504 per half (|x| < 1.3e5 stays exact) and
-    the low half goes subnormal below |x| ~ 1e-4, where the absolute error is < 1e-7.
+    magnitude is what reaches the MLP). The fp16 pair carries 22 bits while |operand| <= 65504; a tile in which a feature
+    or a hidden activation exceeds that is evaluated again scaled by a power of two (exact: the network is positively
+    homogeneous once the biases are scaled along, enarf_query.h mlp_tile), so the mode has fp32's range - x 1e4 and
+    x 1e6 exercise that path (|feature| up to 1.4e5 / 1.4e7). The low half goes subnormal below |x| ~ 1e-4, where the
+    absolute error is < 1e-7.
 
     Bound: 1e-4 against the fp32 oracle while fp32 itself is that well conditioned. At feature magnitudes of 1e2 and more
     it is not - the oracle in fp32 moves by 1e-3 ... 7e-3 against the same oracle in fp64 on a few tenths of a per cent of

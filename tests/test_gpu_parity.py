@@ -166,6 +166,57 @@ def test_query_vs_oracle_and_golden(ops, name, mode):
                  "colour vs reference", tol)
 
 
+def _cube_face_points(sc, per=30000, seed=11):
+    """(1, 3, N) camera-space points (fp32) aimed, in fp64, at the faces / edges / corners of every part's canonical cube
+    (kept where the local cube test can pass: only some parts' canonical faces lie inside their local cube) and of every
+    part's local cube; the snapped coordinates are 1, 1 - 2^-24, 1 - 2^-23, 1 - 2^-21 or 1 + 2^-23 in magnitude."""
+    g = torch.Generator().manual_seed(seed)
+    P = sc.P
+    Rc, tc = sc.cpose[:, :3, :3].double(), sc.cpose[:, :3, 3].double()
+    R, t = sc.pose_scaled[0, :, :3, :3].double(), sc.pose_scaled[0, :, :3, 3].double()
+    scale = sc.scale[0].double()[:, None, None]
+
+    def snapped(n):
+        x = torch.rand(P, n, 3, generator=g, dtype=torch.float64) * 2 - 1
+        eps = torch.tensor([0.0, 2.0 ** -24, 2.0 ** -23, 2.0 ** -21, -2.0 ** -23], dtype=torch.float64)[
+            torch.randint(0, 5, (P, n, 3), generator=g)]
+        snap = torch.rand(P, n, 3, generator=g) < 0.45
+        snap[..., 0] |= ~snap.any(-1)                                        # at least one coordinate on a face
+        sign = torch.where(torch.rand(P, n, 3, generator=g) < 0.5, -1.0, 1.0).double()
+        return torch.where(snap, sign * (1.0 - eps), x)
+    c = snapped(per)
+    local_c = torch.einsum("pji,pnj->pni", Rc, c - tc[:, None]) / scale
+    keep = (local_c.abs() <= 1).all(-1)
+    local_l = snapped(per // 30)
+    local = torch.cat([local_c[keep].reshape(-1, 3), local_l.reshape(-1, 3)])
+    part = torch.cat([torch.arange(P)[:, None].expand(P, per)[keep], torch.arange(P)[:, None].expand(P, per // 30).reshape(-1)])
+    cam = torch.einsum("nij,nj->ni", R[part], local) + t[part]
+    return cam.t()[None].float().contiguous()
+
+
+@pytest.mark.parametrize("mode", ["f32", "f16x3"])
+def test_query_points_on_the_faces_of_the_canonical_cube(ops, mode):
+    """Points whose canonical coordinates sit on, or a few ulp inside / outside, the faces, edges and corners of a part's
+    cube - where the bilinear footprint's upper tap is texel W (its weight is 0; its address must still be legal,
+    enarf_device.h make_taps) and where validity flips. Targets are built in canonical space and mapped back to camera
+    space in fp64; validity and canonical coordinates must match the oracle bit for bit, values within the parity bound."""
+    sc = Scene(32, 1, "center_fixed", 20)
+    ds = DeviceScene(sc)
+    pts = _cube_face_points(sc)
+    den, col, vb, dc, dw = ds.query(pts, mlp_mode=mode, debug=True)
+    oden, ocol, ovalid, taps = O.query(pts, sc.pose_scaled, sc.scale, sc.cpose, sc.raw["tri_plane"], sc.weights(), return_taps=True)
+    near_face = (taps["canonical"].abs().amax(dim=2) > 1 - 1e-6) & ovalid                      # (B, P, N)
+    near_local = (taps["local"].abs().amax(dim=2) > 1 - 1e-6) & ovalid
+    just_out = ((taps["canonical"].abs().amax(dim=2) - 1).abs() < 1e-6) & ~ovalid
+    assert int(near_face.sum()) > 300 and int(near_local.sum()) > 300 and int(just_out.sum()) > 300, \
+        (int(near_face.sum()), int(near_local.sum()), int(just_out.sum()))
+    assert np.array_equal(_cpu(vb).numpy().view(np.uint32), bits_of(ovalid))
+    assert torch.equal(_cpu(dc), taps["canonical"])
+    assert torch.isfinite(den).all() and torch.isfinite(col).all()
+    assert_close(_cpu(den), oden, "density on the faces", MODE_TOL[mode])
+    assert_close(_cpu(col), ocol, "colour on the faces", MODE_TOL[mode])
+
+
 def test_query_bf16_mode_is_close(ops):
     g = load_golden("query_b2_p23")
     sc = Scene(64, 2, "center_fixed", 256)
@@ -478,6 +529,31 @@ def test_render_sample_count_variants_vs_oracle(ops, Nc, Nf):
     assert_close(_cpu(out.color), rc, f"colour Nc={Nc} Nf={Nf}")
     assert_close(_cpu(out.mask), rm, f"mask Nc={Nc} Nf={Nf}")
     assert_close(_cpu(out.disparity), rd, f"disparity Nc={Nc} Nf={Nf}")
+
+
+@pytest.mark.parametrize("S,B,Nc,Nf,n0,nr", [(64, 1, 48, 64, 0, 4096), (32, 3, 24, 32, 5, 333), (32, 1, 72, 96, 300, 400),
+                                            (32, 2, 100, 70, 0, 1024), (32, 1, 2, 2, 16 * 32 + 16, 1), (32, 1, 16, 128, 200, 65)])
+def test_both_march_kernels_give_the_same_bits(ops, S, B, Nc, Nf, n0, nr):
+    """ENARF_MARCH_RAY (a 4-wave workgroup per ray) and ENARF_MARCH_TASK (16-sample tiles as tasks, several rays in
+    flight) share every stage; whichever `auto` picks, colour, mask, disparity, the fine outputs, the drawn bins and
+    the work counters are equal bit for bit - with in-kernel importance sampling, early termination, ragged ray counts,
+    batches (image switches drain the task pipeline), one ray, two samples per lane."""
+    sc = Scene(S, B, "center_fixed", 20)
+    ds = DeviceScene(sc)
+    coord = sc.raw["image_coord"][..., n0:n0 + nr].contiguous()
+    for kw in (dict(seed=5), dict(seed=5, early_stop_eps=1e-3), dict(seed=9, mlp_mode="f16x3")):
+        a = ds.render(coord, Nc, Nf, None, count=True, return_bins=True, march="ray", **kw)
+        b = ds.render(coord, Nc, Nf, None, count=True, return_bins=True, march="task", **kw)
+        c = ds.render(coord, Nc, Nf, None, count=True, return_bins=True, **kw)
+        for other in (b, c):
+            for name in ("color", "mask", "disparity", "fine_weights", "fine_depth"):
+                assert torch.equal(getattr(a, name), getattr(other, name)), (name, kw)
+            assert torch.equal(a.taps["bins"], other.taps["bins"]), kw
+            assert torch.equal(a.counters[:5], other.counters[:5]), (kw, a.counters, other.counters)
+        assert int(_cpu(a.counters)[7]) == 0 and int(_cpu(b.counters)[7]) == 0        # no watchdog exit
+    assert nr < 100 or float(a.mask.max()) > 0.05
+    with pytest.raises(KeyError):
+        ds.render(coord, Nc, Nf, None, march="fastest")
 
 
 def test_steps_on_two_streams_do_not_interfere(ops):

@@ -37,7 +37,8 @@ def test_struct_layouts_match_the_header():
     import tempfile
     from enarf_gan_amd import _lib
     fields = {"enarf_render_args": ("RenderArgs", ["B", "render_scale", "image_coord", "feat_batch_stride", "seed",
-                                                    "fine_depth", "dbg_bins", "counters", "workspace"]),
+                                                    "fine_depth", "dbg_bins", "counters", "workspace", "clamp_mask",
+                                                    "march", "ws_epoch"]),
               "enarf_query_args": ("QueryArgs", ["N", "P", "points", "mask_batch_stride", "dbg_weight"]),
               "enarf_prepare_args": ("PrepareArgs", ["coordinate_scale", "parents", "pose_to_camera", "bias", "mlp_pack"])}
     prog = ['#include "enarf_hip.h"', "#include <stdio.h>", "#include <stddef.h>", "int main(void){"]
