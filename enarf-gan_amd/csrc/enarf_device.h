@@ -214,6 +214,18 @@ __device__ __forceinline__ float exact_dot3(float a0, float b0, float a1, float 
 }
 
 // ---- bilinear sampling (ATen grid_sampler_2d, bilinear / zeros / align_corners=False) --------------
+#ifndef ENARF_DIAG_NOMUL24      // A/B only
+#define ENARF_DIAG_NOMUL24 0
+#endif
+// row * width for plane coordinates: both far below 2^23 (validated on the host), so the full-rate 24-bit multiply does
+// (v_mul_lo_u32 issues at a quarter of the rate)
+__host__ __device__ __forceinline__ int mul_rc(int a, int b) {
+#if defined(__HIP_DEVICE_COMPILE__) && !ENARF_DIAG_NOMUL24
+    return __mul24(a, b);
+#else
+    return a * b;
+#endif
+}
 struct Taps {
     int o00, o01, o10, o11;        // y*W + x of nw, ne, sw, se (clamped in-bounds)
     float w00, w01, w10, w11;      // weights, zeroed for out-of-bounds taps
@@ -236,7 +248,8 @@ __host__ __device__ __forceinline__ Taps make_taps(float x, float y, int H, int 
     const bool by0 = (y0 >= 0) & (y0 < H), by1 = (y1 >= 0) & (y1 < H);
     const int cx0 = min(max(x0, 0), W - 1), cx1 = min(max(x1, 0), W - 1);
     const int cy0 = min(max(y0, 0), H - 1), cy1 = min(max(y1, 0), H - 1);
-    t.o00 = cy0 * W + cx0; t.o01 = cy0 * W + cx1; t.o10 = cy1 * W + cx0; t.o11 = cy1 * W + cx1;
+    const int r0 = mul_rc(cy0, W), r1 = mul_rc(cy1, W);
+    t.o00 = r0 + cx0; t.o01 = r0 + cx1; t.o10 = r1 + cx0; t.o11 = r1 + cx1;
     // out-of-bounds taps weigh zero: zero the axis factor (all factors are >= 0, so the products are the same bits)
     const float zx0 = bx0 ? ax0 : 0.0f, zx1 = bx1 ? ax1 : 0.0f, zy0 = by0 ? ay0 : 0.0f, zy1 = by1 ? ay1 : 0.0f;
     t.w00 = zx0 * zy0;
@@ -270,7 +283,7 @@ __host__ __device__ __forceinline__ Taps make_taps_valid(float x, float y, int H
     const float ay1 = iy - fy, ay0 = (fy + 1.0f) - iy;
     const int cx0 = max(x0, 0), cx1 = min(x1, W - 1);
     const int cy0 = max(y0, 0), cy1 = min(y1, H - 1);
-    const int r0 = cy0 * W, r1 = cy1 * W;
+    const int r0 = mul_rc(cy0, W), r1 = mul_rc(cy1, W);
     t.o00 = r0 + cx0; t.o01 = r0 + cx1; t.o10 = r1 + cx0; t.o11 = r1 + cx1;
     const float zx0 = (x0 >= 0) ? ax0 : 0.0f, zx1 = (x1 < W) ? ax1 : 0.0f;
     const float zy0 = (y0 >= 0) ? ay0 : 0.0f, zy1 = (y1 < H) ? ay1 : 0.0f;

@@ -703,7 +703,7 @@ __device__ __forceinline__ void query_tile(const QueryCtx &S, const int *cand_li
         if (act_c) {   // quad-uniform, so the quad broadcasts see all four lanes
             const int gm = (g == 3) ? 0 : g;
             const char *maskb = reinterpret_cast<const char *>(S.mask);
-            const unsigned moff = ((unsigned)(3 * k_c + gm) * (unsigned)mplane) << 2;
+            const unsigned moff = __umul24((unsigned)(3 * k_c + gm), (unsigned)mplane) << 2;
 #if ENARF_MASK_ROW_PAIRS
             // the four part-probability taps as two 8-byte row pairs: the texture path charges a load instruction by the
             // cache lines it touches (48 here: 16 quads x 3 planes), not by its width - two instructions instead of four
@@ -804,7 +804,7 @@ __device__ __forceinline__ void query_tile(const QueryCtx &S, const int *cand_li
         if (act) {   // quad-uniform, so the quad broadcasts below see all four lanes
             const int gm = (g == 3) ? 0 : g;   // lane 3 repeats plane 0 (same addresses as lane 0: no extra traffic)
             const char *maskb = reinterpret_cast<const char *>(S.mask);
-            const unsigned moff = ((unsigned)(3 * k + gm) * (unsigned)mplane) << 2;
+            const unsigned moff = (ENARF_DIAG_NOMUL24 ? (unsigned)(3 * k + gm) * (unsigned)mplane : __umul24((unsigned)(3 * k + gm), (unsigned)mplane)) << 2;   // < 2^32 bytes, mplane < 2^24: check_common
 #if ENARF_MASK_ROW_PAIRS
             // the four part-probability taps as two 8-byte row pairs: the texture path charges a load instruction by the
             // cache lines it touches (48 here: 16 quads x 3 planes), not by its width - two instructions instead of four

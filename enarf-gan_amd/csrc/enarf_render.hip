@@ -953,6 +953,10 @@ static int check_common(const char *who, int B, int P, int H, int W, int mode, c
                         const void *feat, const void *mask, const void *pack) {
     if (B <= 0 || P <= 0 || P > ENARF_MAX_PARTS) return host::fail(ENARF_ERR_ARG, "%s: bad B=%d or P=%d (max %d parts)", who, B, P, ENARF_MAX_PARTS);
     if (H <= 0 || W <= 0) return host::fail(ENARF_ERR_ARG, "%s: bad plane size %dx%d", who, H, W);
+    // 32-bit byte offsets inside one image's planes (and 24-bit row * width products): 3 P part-probability planes of 4 B,
+    // 3 feature planes of 128 B per texel
+    if ((unsigned long long)3 * P * H * W * 4 >= (1ull << 32) || (unsigned long long)3 * H * W * 128 >= (1ull << 31) || H >= (1 << 23) || W >= (1 << 23))
+        return host::fail(ENARF_ERR_UNSUPPORTED, "%s: planes of %dx%d with %d parts exceed the 32-bit in-image offsets", who, H, W, P);
     if (mode < 0 || mode > 3) return host::fail(ENARF_ERR_ARG, "%s: bad mlp_mode %d", who, mode);
     if (!parts || !canon || !feat || !mask || !pack) return host::fail(ENARF_ERR_ARG, "%s: null input pointer", who);
     return 0;

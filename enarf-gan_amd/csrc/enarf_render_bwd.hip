@@ -830,6 +830,7 @@ extern "C" int enarf_render_bwd(const enarf_render_bwd_args *args, enarf_stream_
     const enarf_render_bwd_args &a = *args;
     if (a.B <= 0 || a.n <= 0 || a.P <= 0 || a.P > ENARF_MAX_PARTS || a.H <= 0 || a.W <= 0)
         return host::fail(ENARF_ERR_ARG, "enarf_render_bwd: bad sizes");
+    if (a.H >= (1 << 23) || a.W >= (1 << 23)) return host::fail(ENARF_ERR_UNSUPPORTED, "enarf_render_bwd: plane side >= 2^23");
     if (a.Nf < 2 || a.Nf > kBwdMaxSamples) return host::fail(ENARF_ERR_UNSUPPORTED, "enarf_render_bwd: Nf=%d outside [2, %d]", a.Nf, kBwdMaxSamples);
     if (!a.image_coord || !a.inv_intrinsics || !a.parts || !a.canonical_pose || !a.feat_cl || !a.mask_planes || !a.mlp_pack ||
         !a.bins || !a.grad_feat_cl || !a.grad_mask_planes || !a.rows_x || !a.rows_h1 || !a.rows_h2 || !a.rows_dz1 ||
@@ -867,6 +868,7 @@ extern "C" int enarf_query_bwd(const enarf_query_bwd_args *args, enarf_stream_t 
     const enarf_query_bwd_args &a = *args;
     if (a.B <= 0 || a.B > 65535 || a.N < 0 || a.P <= 0 || a.P > ENARF_MAX_PARTS || a.H <= 0 || a.W <= 0)
         return host::fail(ENARF_ERR_ARG, "enarf_query_bwd: bad sizes");
+    if (a.H >= (1 << 23) || a.W >= (1 << 23)) return host::fail(ENARF_ERR_UNSUPPORTED, "enarf_query_bwd: plane side >= 2^23");
     if (!a.points || !a.parts || !a.canonical_pose || !a.feat_cl || !a.mask_planes || !a.mlp_pack || !a.grad_feat_cl ||
         !a.grad_mask_planes || !a.rows_x || !a.rows_h1 || !a.rows_h2 || !a.rows_dz1 || !a.rows_dz2 || !a.rows_dz3 || !a.row_blocks)
         return host::fail(ENARF_ERR_ARG, "enarf_query_bwd: null pointer");

@@ -355,7 +355,7 @@ __device__ __forceinline__ void ray_tile_task(const enarf_render_args &a, const 
                                               int t, int lane, MarchCounters &C) {
     const int Nc = a.Nc, Nf = a.Nf, n = a.n;
     const RayRec rec = *reinterpret_cast<const RayRec *>(sw + SL_REC);
-    const uint32_t rid = sw[SL_RID];
+    const uint32_t rid = (uint32_t)__builtin_amdgcn_readfirstlane((int)sw[SL_RID]);      // wave-uniform: plane bases in SGPRs
     const int b = (int)(rid / (uint32_t)n);
     S.feat = a.feat_cl + (size_t)b * a.feat_batch_stride;
     S.mask = a.mask_planes + (size_t)b * a.mask_batch_stride;
