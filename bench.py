@@ -34,6 +34,7 @@ HBM_PEAK_GBS = 8000.0
 L2_PEAK_GBS = 34500.0
 NUM_CUS = 256
 L1_BYTES_PER_CLK_PER_CU = 64.0
+UB_TA_SHAPE_GBS = 32060.0     # tools/ub_ta.hip, pattern 1, all quads active (profiles/r02_ub_ta.txt)
 BF16_DENSE_TFLOPS = 2500.0
 C3_GLOBAL_FRAMES = 64
 
@@ -365,13 +366,24 @@ def main():
         clock_ghz = 2.4
         l1_peak = NUM_CUS * L1_BYTES_PER_CLK_PER_CU * clock_ghz          # GB/s: what the CUs' texture paths can deliver
         workload_key = f"C1:{S}:{B}:{Nc}:{Nf}:{P}:{args.mlp_mode}:{int(distinct)}:{args.early_stop_eps}"
+        if args.march != "auto":
+            workload_key += f":{args.march}"
+        # which of the two march kernels ran (enarf_render.hip launch_render: ENARF_MARCH_AUTO picks by shape)
+        spl = 2 if (Nc > 64 or Nf > 64) else 1
+        task = args.march == "task" or (args.march == "auto" and spl == 2 and B == 1)
+        mode_id = {"f32": 0, "bf16x3": 1, "bf16": 2, "f16x3": 3}[args.mlp_mode]
+        kernel_name = f"enarf::march_kernel<{mode_id}, {spl}, 12>" if task else f"enarf::render_kernel<{mode_id}, {spl}>"
         roof = {
             # the texel gathers are L1/L2 hits (the tri-plane is read from HBM once): the roofline that bounds the march is
             # the CUs' vector-memory (texture) path, not HBM. `achieved` = algorithmic texel bytes / kernel time.
-            "bound": "l1-texture-path", "kernel": "enarf::march_kernel",
+            "bound": "l1-texture-path", "kernel": kernel_name,
             "achieved": gather_bytes / t_k / 1e9, "peak": l1_peak, "unit": "GB/s", "frac": gather_bytes / t_k / 1e9 / l1_peak,
             "peak_note": f"{NUM_CUS} CUs x {L1_BYTES_PER_CLK_PER_CU:.0f} B/clk x {clock_ghz} GHz (MI355X_MICROARCH.md: 16-B-per-lane loads "
                          "take 16 clk per wave instruction)",
+            # what the same path sustains for exactly this access shape (2x2 footprints of 128-B texels read by quads, 12
+            # waves per CU), measured by tools/ub_ta.hip on this GPU model: profiles/r02_ub_ta.txt, pattern 1, 16/16 quads
+            "shape_ceiling": {"value": UB_TA_SHAPE_GBS, "unit": "GB/s", "frac": gather_bytes / t_k / 1e9 / UB_TA_SHAPE_GBS,
+                              "source": "profiles/r02_ub_ta.txt"},
             "kernel_ms": kern_ms, "gather_bytes_per_launch": gather_bytes, "compulsory_hbm_bytes_per_launch": compulsory,
             "hbm_frac_if_every_gather_missed": (gather_bytes + compulsory) / t_k / 1e9 / HBM_PEAK_GBS,
             "compulsory_hbm_frac": compulsory / t_k / 1e9 / HBM_PEAK_GBS,

@@ -6,7 +6,7 @@ from collections import defaultdict
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "pmc_final")
 tag = sys.argv[1]
-names = {"march_kernel": "march", "render_kernel": "march", "pre_march_kernel": "pre", "ray_setup_kernel": "setup"}
+names = {"enarf::march_kernel<": "march", "enarf::render_kernel<": "march", "enarf::pre_march_kernel": "pre", "ray_setup_kernel": "setup"}
 lines = ["# rocprofv3 --pmc (one group per run, with --kernel-trace only) on: python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-p24 --spinup-ms 0",
          "# workload C1: 128x128 rays, B=1, Nc 48 + Nf 64, P=23, f16x3; mean over the launches of each kernel",
          "# march = enarf::render_kernel<3,1>, pre = enarf::pre_march_kernel (re-layout + prepare + ray set-up); SQ_* cycle counters are quad-cycles (x4 = cycles)",
@@ -44,7 +44,7 @@ def kernel_avg_ns(stats_csv, key):
 
 
 if st and ("march", "SQ_WAVE_CYCLES") in vals:
-    t_ns = kernel_avg_ns(st[-1], "march_kernel") or kernel_avg_ns(st[-1], "render_kernel")
+    t_ns = kernel_avg_ns(st[-1], "enarf::march_kernel<") or kernel_avg_ns(st[-1], "enarf::render_kernel<")
     t = t_ns * 1e-9
     g = lambda c: vals.get(("march", c), 0.0)
     # persistent waves live for the whole launch: their mean lifetime in shader cycles is the launch's cycle count
