@@ -30,6 +30,14 @@ class _RendererShell(nn.Module):
         self.nerf = TriPlaneNARF(params, z_dim=z_dim, num_bone=num_bone, bone_length=True, parent=parent_id,
                                  num_bone_param=n_param, **nerf_kwargs)
 
+    @property
+    def memory_cost(self):
+        return self.nerf.memory_cost
+
+    @property
+    def flops(self):
+        return self.nerf.flops
+
     def register_canonical_pose(self, pose: np.ndarray):
         self.nerf.register_canonical_pose(pose)
 

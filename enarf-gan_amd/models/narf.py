@@ -131,6 +131,19 @@ class TriPlaneNARF(nn.Module):
         self._cl_cache = None              # (data_ptr, _version, shape) -> channel-last copy of a constant tri-plane
 
     # ---- canonical pose (models/narf.py:84-120) -------------------------------------------------------------------
+    @property
+    def memory_cost(self) -> int:
+        """Activations per query point in the reference's units (output channels of every conv layer,
+        libraries/custom_stylegan2/net.py:98-100): the StyledMLP's 64 + 64 + 4. (The reference's own
+        TriPlaneNeRF.memory_cost, libraries/triplane/triplane_nerf.py:73-79, raises AttributeError on its StyledMLP child.)"""
+        return sum(layer.conv.weight.shape[1] for layer in self.mlp.layers)
+
+    @property
+    def flops(self) -> int:
+        """Multiply-adds x 2 of the per-point network (2 * in * out - out + bias, net.py:102-107, per layer): the
+        32 -> 64 -> 64 -> 4 StyledMLP = 12 800 - the MFMA-eligible work SURVEY.md section 8(d) prices a query at."""
+        return sum(2 * layer.conv.weight.shape[2] * layer.conv.weight.shape[1] for layer in self.mlp.layers)
+
     def register_canonical_pose(self, pose: np.ndarray) -> None:
         pose = np.asarray(pose)
         par = self.parent_id[1:]

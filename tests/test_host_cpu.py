@@ -176,6 +176,7 @@ def test_model_mirror_keeps_reference_names_and_state_dict_keys():
                            black_background=True)
     assert gan.nerf.num_bone == 24 and gan.nerf.tri_plane.shape[1] == 32 * 3 + 24 * 3
     assert gan.nerf.mlp.layers[0].conv.modulation.weight.shape == (32, 256)
+    assert gan.flops == 12800 and g.flops == 12800 and gan.memory_cost == 132          # per query point
 
 
 def test_mesh_api_fails_like_the_reference_without_its_third_party_stages():

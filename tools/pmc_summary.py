@@ -1,11 +1,13 @@
 """Summarise gpurun_out/pmc_final (tools/gpu_pmc.sh) into profiles/<tag>_pmc_summary.txt, profiles/<tag>_kernel_stats.csv
-and profiles/traffic.json. Usage: python tools/pmc_summary.py r01_final"""
+and profiles/traffic.json. Usage: python tools/pmc_summary.py r01_final [gpurun_out subdirectory, default pmc_final; WORKLOAD_KEY=... for a non-default workload]"""
 import csv, glob, json, os, shutil, sys
 from collections import defaultdict
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(root, "gpurun_out", "pmc_final")
 tag = sys.argv[1]
+sub = sys.argv[2] if len(sys.argv) > 2 else "pmc_final"
+src = os.path.join(root, "gpurun_out", sub)
+default_workload = sub == "pmc_final"           # only the default C1 profile feeds bench.py (traffic.json, r02_roofline.json)
 names = {"enarf::march_kernel<": "march", "enarf::render_kernel<": "march", "enarf::pre_march_kernel": "pre", "ray_setup_kernel": "setup"}
 lines = ["# rocprofv3 --pmc (one group per run, with --kernel-trace only) on: python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-p24 --spinup-ms 0",
          "# workload C1: 128x128 rays, B=1, Nc 48 + Nf 64, P=23, f16x3; mean over the launches of each kernel",
@@ -28,7 +30,7 @@ open(os.path.join(root, "profiles", f"{tag}_pmc_summary.txt"), "w").write("\n".j
 st = sorted(glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv")), key=os.path.getmtime)
 if st:
     shutil.copy(st[-1], os.path.join(root, "profiles", f"{tag}_kernel_stats.csv"))
-if ("march", "FETCH_SIZE") in vals:
+if ("march", "FETCH_SIZE") in vals and default_workload:
     fetch, write = vals[("march", "FETCH_SIZE")], vals.get(("march", "WRITE_SIZE"), 0.0)
     json.dump({"render_kernel_hbm_bytes_per_launch": int((2 * fetch + write) * 1024), "fetch_size_kb_raw": fetch,
                "write_size_kb": write,
@@ -67,5 +69,5 @@ if st and ("march", "SQ_WAVE_CYCLES") in vals:
     json.dump({"workload_key": os.environ.get("WORKLOAD_KEY", "C1:128:1:48:64:23:f16x3:0:0.0"), "kernel_ms": t_ns * 1e-6, "cycles_per_launch": cycles,
                "clock_ghz_under_profiler": cycles / t / 1e9, "hbm_bytes_per_launch": int(hbm_bytes), "limiter": limiter, "fractions": fr,
                "kernel_stats": f"profiles/{tag}_kernel_stats.csv"},
-              open(os.path.join(root, "profiles", "r02_roofline.json"), "w"), indent=1)
+              open(os.path.join(root, "profiles", "r02_roofline.json" if default_workload else f"{tag}_roofline.json"), "w"), indent=1)
 print("\n".join(lines[4:]))
