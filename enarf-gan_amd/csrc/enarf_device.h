@@ -326,17 +326,37 @@ __device__ __forceinline__ float styled_act(float v) {
 
 // ---- NCHW -> channel-last re-layout of one (b, plane, row, 64-column) block ----------------------------------------------
 // in: (B, in_ch_total, H, W), planes p = 0..2 at channels [p*C, (p+1)*C); out: [b][p][y][x][C]; tile: C*65 floats of LDS.
-// Coalesced 256-B reads along x, contiguous 64*C*4-B writes.
+// Full blocks of aligned planes move 16 B per lane both ways (x-runs of 4 in, channel-runs of 4 out) through the padded
+// tile; ragged blocks, odd widths and unaligned tensors take the 4-byte path.
 template <int C>
 __device__ __forceinline__ void pack_block(const float *__restrict__ in, float *__restrict__ out, int in_ch_total, int H,
                                            int W, int xblk, int y, int bp, int tid, float *tile) {
     const int xb = xblk * 64, b = bp / 3, p = bp % 3;
     const float *src = in + (((size_t)b * in_ch_total + p * C) * H + y) * W;
+    float *dst = out + ((((size_t)b * 3 + p) * H + y) * W + xb) * C;
+    const bool wide = (C % 4 == 0) && (W % 4 == 0) && (xb + 64 <= W) &&
+                      (((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15u) == 0);      // block-uniform
+    if (wide) {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        for (int v = tid; v < C * 16; v += 256) {
+            const int c = v >> 4, x4 = (v & 15) << 2;
+            const f4 q = *reinterpret_cast<const f4 *>(src + (size_t)c * H * W + xb + x4);
+            float *t = tile + c * 65 + x4;
+            t[0] = q[0]; t[1] = q[1]; t[2] = q[2]; t[3] = q[3];
+        }
+        __syncthreads();
+        constexpr int C4 = C / 4 > 0 ? C / 4 : 1;
+        for (int v = tid; v < 64 * C4; v += 256) {
+            const int x = v / C4, c = (v % C4) << 2;
+            const float *t = tile + c * 65 + x;
+            *reinterpret_cast<f4 *>(dst + x * C + c) = f4{t[0], t[65], t[130], t[195]};
+        }
+        return;
+    }
     const int x = tid & 63;
     for (int c = tid >> 6; c < C; c += 4)
         tile[c * 65 + x] = (xb + x < W) ? src[(size_t)c * H * W + xb + x] : 0.0f;
     __syncthreads();
-    float *dst = out + ((((size_t)b * 3 + p) * H + y) * W + xb) * C;
     const int nvalid = min(64, W - xb) * C;
     for (int o = tid; o < nvalid; o += 256) dst[o] = tile[(o % C) * 65 + (o / C)];
 }

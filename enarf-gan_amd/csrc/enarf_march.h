@@ -91,12 +91,33 @@ __device__ __forceinline__ void ws_clear_other_header(void *workspace, int epoch
     unsigned int *o = reinterpret_cast<unsigned int *>(reinterpret_cast<char *>(workspace) + ws_other_header_off(epoch));
     for (int i = tid; i < kWsHeaderBytes / 4; i += 256) o[i] = 0u;
 }
-// Bands are cut in the padded ray index b * npad + ray (npad = 64 * set-up blocks per image), in multiples of 64, so
-// that the 64 rays of one set-up block always fall into one band.
+// Bands: every image's rays (padded to npad = 64 * set-up blocks per image) are cut into kQueues contiguous row bands in
+// multiples of 64, so that the 64 rays of one set-up block always fall into one band; band q of EVERY image of the batch
+// is filed in the lists of queue q (XCD q's home). With one image per launch that is the image's q-th eighth; with a
+// batch each XCD still works on the same eighth of each frame - a texel working set its 4 MB L2 can hold - instead of on
+// whole frames (ENARF_IMAGE_BANDS=1, the round-1 cut: bands of the concatenated batch; A/B only).
+#ifndef ENARF_IMAGE_BANDS
+#define ENARF_IMAGE_BANDS 0
+#endif
 __host__ __device__ inline long long ws_npad(int n) { return 64ll * ((n + 63) / 64); }
-__host__ __device__ inline long long ws_band_size(int B, int n) {
+__host__ __device__ inline long long ws_image_band(int n) {          // rays of one image per band
+    return 64ll * ((ws_npad(n) + 64ll * kQueues - 1) / (64ll * kQueues));
+}
+__host__ __device__ inline long long ws_band_size(int B, int n) {     // capacity of one (band, class) list
+#if ENARF_IMAGE_BANDS
     const long long tot = (long long)B * ws_npad(n);
     return 64ll * ((tot + 64ll * kQueues - 1) / (64ll * kQueues));
+#else
+    return (long long)B * ws_image_band(n);
+#endif
+}
+// band of set-up block `blk` of image b
+__host__ __device__ inline int ws_band_of(int B, int n, int b, int blk) {
+#if ENARF_IMAGE_BANDS
+    return (int)(((long long)b * ws_npad(n) + 64ll * blk) / ws_band_size(B, n));
+#else
+    return (int)((64ll * blk) / ws_image_band(n));
+#endif
 }
 __host__ __device__ inline size_t ws_total_bytes(int B, int n) {
     return ws_list_off((long long)B * n) + (size_t)kQueues * kClasses * (size_t)ws_band_size(B, n) * sizeof(uint32_t);
@@ -121,8 +142,8 @@ __device__ __forceinline__ int build_cand_list(int *list, uint32_t set, int lane
 }
 
 // ---- XCD-affine, heaviest-first ray queues --------------------------------------------------------------------------
-// The rays are cut into 8 contiguous bands (ws_band_size), one per XCD; within a band the set-up pass files every live
-// ray under its cost class: kQueues x kClasses lists, each with its own queue head. A workgroup works through the
+// Every image is cut into 8 contiguous row bands (ws_image_band), one per XCD; within a band the set-up pass files every
+// live ray (of every image of the batch) under its cost class: kQueues x kClasses lists, each with its own queue head. A workgroup works through the
 // classes heaviest first; within a class it pulls from the band of the XCD it runs on (HW_REG_XCC_ID) and, when that
 // list is drained, from the other bands' lists of the same class in turn.
 //  * heaviest first, chip-wide: ray cost spans 10x (1 .. 14 gather rounds per tile) and the heavy rays sit in a few

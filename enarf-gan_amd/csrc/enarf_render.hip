@@ -450,7 +450,7 @@ __device__ __forceinline__ void ray_setup_block(const enarf_render_args &a, cons
         if (lane == 0) l_cnt[wave * kClasses + c] = __popcll(bal[c]);
     }
     const long long band = ws_band_size(a.B, n);
-    const int q = (int)(((long long)b * ws_npad(n) + 64ll * blk) / band);
+    const int q = ws_band_of(a.B, n, b, blk);
     unsigned int *wsh = reinterpret_cast<unsigned int *>(reinterpret_cast<char *>(a.workspace) + ws_header_off(a.ws_epoch));
     __syncthreads();
     if (tid < kClasses) {

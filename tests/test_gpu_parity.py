@@ -52,6 +52,16 @@ def test_triplane_pack_is_a_pure_permutation(ops):
     cl = _cpu(ops.triplane_pack(tri))
     ref = sc.raw["tri_plane"][:, :96].reshape(2, 3, 32, 256, 256).permute(0, 1, 3, 4, 2)
     assert torch.equal(cl, ref)
+    # ragged widths (4-byte path: W not a multiple of 4, and a last block narrower than 64) and an unaligned view
+    g = torch.Generator().manual_seed(0)
+    for H, W in ((5, 70), (3, 132), (2, 64)):
+        t = torch.randn(1, 96 + 6, H, W, generator=g)
+        want = t[:, :96].reshape(1, 3, 32, H, W).permute(0, 1, 3, 4, 2)
+        assert torch.equal(_cpu(ops.triplane_pack(t.cuda())), want), (H, W)
+    flat = torch.randn(1 + 102 * 4 * 64, generator=g).cuda()
+    odd = flat[1:].reshape(1, 102, 4, 64)                     # data pointer 4 bytes off a 16-byte boundary
+    assert odd.data_ptr() % 16 == 4
+    assert torch.equal(_cpu(ops.triplane_pack(odd)), _cpu(odd)[:, :96].reshape(1, 3, 32, 4, 64).permute(0, 1, 3, 4, 2))
 
 
 # --------------------------------------------------------------------------------------------- a1 operator
