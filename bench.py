@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--mlp-mode", default="f16x3", choices=["f32", "f16x3", "bf16x3", "bf16"])
     ap.add_argument("--march", default="auto", choices=["auto", "ray", "task"],
                     help="which march kernel (ENARF_MARCH_*): auto picks by shape; both give the same bits")
+    ap.add_argument("--drop-missed-rays", action="store_true",
+                    help="measurement only: drop rays that hit no cube also for B > 1 (the reference does so for B == 1 only)")
     ap.add_argument("--style-dim", type=int, default=20)
     ap.add_argument("--early-stop-eps", type=float, default=0.0, help="opt-in early ray termination (0 = exact)")
     ap.add_argument("--cache-triplane", action="store_true", help="re-lay the (constant) tri-plane once instead of every step")
@@ -208,7 +210,7 @@ def main():
                               3.0, coord, d["inv_intrinsics"], cpose_d, tri, f, Nc, Nf, parts_out=pa,
                               pack_out=pk, relayout=not args.cache_triplane, seed=seed, mlp_mode=mode or args.mlp_mode,
                               want_fine=True, count=count, early_stop_eps=args.early_stop_eps, return_bins=return_bins,
-                              march=args.march)
+                              march=args.march, drop_invalid_rays=True if args.drop_missed_rays else None)
 
     # ---- the training step (opt-in): forward + backward + gradient all-reduce of the renderer's parameters
     train_params = None

@@ -91,13 +91,13 @@ __device__ __forceinline__ void ws_clear_other_header(void *workspace, int epoch
     unsigned int *o = reinterpret_cast<unsigned int *>(reinterpret_cast<char *>(workspace) + ws_other_header_off(epoch));
     for (int i = tid; i < kWsHeaderBytes / 4; i += 256) o[i] = 0u;
 }
-// Bands: every image's rays (padded to npad = 64 * set-up blocks per image) are cut into kQueues contiguous row bands in
-// multiples of 64, so that the 64 rays of one set-up block always fall into one band; band q of EVERY image of the batch
-// is filed in the lists of queue q (XCD q's home). With one image per launch that is the image's q-th eighth; with a
-// batch each XCD still works on the same eighth of each frame - a texel working set its 4 MB L2 can hold - instead of on
-// whole frames (ENARF_IMAGE_BANDS=1, the round-1 cut: bands of the concatenated batch; A/B only).
+// Bands are cut in the padded ray index b * npad + ray (npad = 64 * set-up blocks per image), in multiples of 64, so
+// that the 64 rays of one set-up block always fall into one band: one image -> its eighths; 8 images -> one image per
+// band (XCD). ENARF_IMAGE_BANDS=0 (A/B only) cuts every image into eighths instead, band q of EVERY image in queue q -
+// a smaller texel working set per XCD, but a workgroup then changes image (restages the MLP pack and part frames)
+// B times per cost class: measured slower on every batch (8 frames 2.08 vs 1.80 ms, 16 distinct 4.69 vs 4.42).
 #ifndef ENARF_IMAGE_BANDS
-#define ENARF_IMAGE_BANDS 0
+#define ENARF_IMAGE_BANDS 1
 #endif
 __host__ __device__ inline long long ws_npad(int n) { return 64ll * ((n + 63) / 64); }
 __host__ __device__ inline long long ws_image_band(int n) {          // rays of one image per band

@@ -10,6 +10,9 @@
 #define ENARF_RENDER_WAVES_PER_SIMD 3
 #endif
 
+#ifndef ENARF_BATCH_CLASSES
+#define ENARF_BATCH_CLASSES 4
+#endif
 namespace enarf {
 
 // =================================================================================================
@@ -441,7 +444,9 @@ __device__ __forceinline__ void ray_setup_block(const enarf_render_args &a, cons
         if (a.fine_depth) for (int i = g; i < Nf; i += 4) a.fine_depth[rid * Nf + i] = 0.0f;
     }
     // file the block's live rays, in ray order, under (band, cost class) - see RayQueue
-    const int cls = ray_cost_class(cand);
+    // more images than bands: a band holds several whole frames, and class-major order would walk each of them once per
+    // class (ENARF_BATCH_CLASSES: how many of the cost classes such batches use; fewer = longer runs on one frame)
+    const int cls = (a.B > kQueues) ? min(ray_cost_class(cand), ENARF_BATCH_CLASSES - 1) : ray_cost_class(cand);
     const bool file_it = live && g == 0;
     uint64_t bal[kClasses];
 #pragma unroll
