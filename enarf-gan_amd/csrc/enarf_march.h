@@ -66,18 +66,22 @@ __device__ __forceinline__ float density_head(float sigma_act, uint32_t bits, fl
 // what the set-up pass leaves for the march: depth range, candidate parts, hit flag and the ray direction K^-1 [u v w]
 struct __attribute__((aligned(16))) RayRec { float dmin, dmax; uint32_t cand, valid; float dx, dy, dz, pad; };
 static_assert(sizeof(RayRec) == 32, "RayRec");
-// workspace: [header kWsHeaderBytes][RayRec x B*n][ray lists: kQueues bands x kClasses cost classes x band_size entries]
-// header (u32): [1] live rays, [kWsCountsOff + q * kClasses + c] entries in list (q, c), [kWsHeadsOff + 16 * (q * kClasses + c)] queue head
-// of list (q, c) - one 64-B slot per head, so that the atomics of different lists do not share a cache line
+// workspace: [header kWsHeaderBytes][RayRec x B*n][ray lists: kNumLists x band_size entries]
+// lists: (band q, cost class c) -> id q * kClasses + c, then one list per band of the live rays WITHOUT any candidate part
+// (id ws_missed_list(q); batches only - a single image drops such rays, rendering.py:107-110): they need no query at all.
+// header (u32): [1] live rays, [kWsCountsOff + id] entries in list id, [kWsHeadsOff + 16 * id] queue head of list id -
+// one 64-B slot per head, so that the atomics of different lists do not share a cache line
 constexpr int kQueues = 8;
 #ifndef ENARF_NUM_CLASSES
 #define ENARF_NUM_CLASSES 4
 #endif
 constexpr int kClasses = ENARF_NUM_CLASSES;
 constexpr int kWsCountsOff = 16;                                     // u32 index of the list lengths
-constexpr int kWsHeadsOff = (kWsCountsOff + kQueues * kClasses + 15) / 16 * 16;   // u32 index of the first queue head
+constexpr int kNumLists = kQueues * (kClasses + 1);
+__host__ __device__ constexpr int ws_missed_list(int q) { return kQueues * kClasses + q; }
+constexpr int kWsHeadsOff = (kWsCountsOff + kNumLists + 15) / 16 * 16;   // u32 index of the first queue head
 constexpr int kWsHeadStride = 16;                                    // u32 per queue head slot
-constexpr int kWsHeaderBytes = (kWsHeadsOff + kQueues * kClasses * kWsHeadStride) * 4;
+constexpr int kWsHeaderBytes = (kWsHeadsOff + kNumLists * kWsHeadStride) * 4;
 // TWO headers, so that nobody has to clear one between launches: the launch with epoch k (> 0) uses header k & 1, which
 // the launch with epoch k - 1 cleared while it was using the other one; epoch 0 = the library clears both with a fill
 // first (always safe; what a caller that does not count its calls passes) and uses header 0.
@@ -120,7 +124,7 @@ __host__ __device__ inline int ws_band_of(int B, int n, int b, int blk) {
 #endif
 }
 __host__ __device__ inline size_t ws_total_bytes(int B, int n) {
-    return ws_list_off((long long)B * n) + (size_t)kQueues * kClasses * (size_t)ws_band_size(B, n) * sizeof(uint32_t);
+    return ws_list_off((long long)B * n) + (size_t)kNumLists * (size_t)ws_band_size(B, n) * sizeof(uint32_t);
 }
 // cost class of a live ray from the number of candidate parts on its marched segment (which tracks the ray's gather
 // rounds closely: correlation 0.98 on the bench frame): 0 = heaviest

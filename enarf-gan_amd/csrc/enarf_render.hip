@@ -309,7 +309,7 @@ __device__ __forceinline__ bool ray_hits_part(const float *F, float dx, float dy
 // for the conservative slab tests and the 32 range-test depths (8 each) for the exact cube tests. Rays the
 // reference drops (batch 1, no cube hit: rendering.py:107-110, :337-350) get their zero outputs here and never
 // enter the march; all others are appended to the live list in blocks that keep image order.
-constexpr int kSetupSmemFloats = ENARF_MAX_PARTS * kLdsPartStride + 32 + 12 + 5 * kClasses;
+constexpr int kSetupSmemFloats = ENARF_MAX_PARTS * kLdsPartStride + 32 + 12 + 5 * (kClasses + 1);
 
 // RAW: the part frames are computed here from the raw joint poses (same arithmetic as prepare_block, so the values
 // are bit-identical to a.parts) - lets set-up blocks run in the same launch as the prepare blocks. (`raw` stays a
@@ -443,35 +443,40 @@ __device__ __forceinline__ void ray_setup_block(const enarf_render_args &a, cons
         if (a.fine_weights) for (int i = g; i < Nf - 1; i += 4) a.fine_weights[rid * (Nf - 1) + i] = 0.0f;
         if (a.fine_depth) for (int i = g; i < Nf; i += 4) a.fine_depth[rid * Nf + i] = 0.0f;
     }
-    // file the block's live rays, in ray order, under (band, cost class) - see RayQueue
+    // file the block's live rays, in ray order, under (band, cost class) - see RayQueue; live rays without a candidate
+    // part (batches only: a single image drops them) go to the band's list of missed rays
+    constexpr int kFile = kClasses + 1;
     // more images than bands: a band holds several whole frames, and class-major order would walk each of them once per
-    // class (ENARF_BATCH_CLASSES: how many of the cost classes such batches use; fewer = longer runs on one frame)
-    const int cls = (a.B > kQueues) ? min(ray_cost_class(cand), ENARF_BATCH_CLASSES - 1) : ray_cost_class(cand);
+    // class (ENARF_BATCH_CLASSES: how many of the cost classes such batches use; measured: no difference)
+    const int cls = (cand == 0u) ? kClasses
+                    : (a.B > kQueues) ? min(ray_cost_class(cand), ENARF_BATCH_CLASSES - 1) : ray_cost_class(cand);
     const bool file_it = live && g == 0;
-    uint64_t bal[kClasses];
+    uint64_t bal[kFile];
 #pragma unroll
-    for (int c = 0; c < kClasses; ++c) {
+    for (int c = 0; c < kFile; ++c) {
         bal[c] = __ballot(file_it && cls == c);
-        if (lane == 0) l_cnt[wave * kClasses + c] = __popcll(bal[c]);
+        if (lane == 0) l_cnt[wave * kFile + c] = __popcll(bal[c]);
     }
     const long long band = ws_band_size(a.B, n);
     const int q = ws_band_of(a.B, n, b, blk);
     unsigned int *wsh = reinterpret_cast<unsigned int *>(reinterpret_cast<char *>(a.workspace) + ws_header_off(a.ws_epoch));
     __syncthreads();
-    if (tid < kClasses) {
-        const int tot = l_cnt[tid] + l_cnt[kClasses + tid] + l_cnt[2 * kClasses + tid] + l_cnt[3 * kClasses + tid];
-        l_cnt[4 * kClasses + tid] = tot ? (int)atomicAdd(wsh + kWsCountsOff + q * kClasses + tid, (unsigned int)tot) : 0;
+    if (tid < kFile) {
+        const int tot = l_cnt[tid] + l_cnt[kFile + tid] + l_cnt[2 * kFile + tid] + l_cnt[3 * kFile + tid];
+        const int lid = (tid < kClasses) ? q * kClasses + tid : ws_missed_list(q);
+        l_cnt[4 * kFile + tid] = tot ? (int)atomicAdd(wsh + kWsCountsOff + lid, (unsigned int)tot) : 0;
         if (tot) atomicAdd(wsh + 1, (unsigned int)tot);
     }
     __syncthreads();
     if (file_it) {
-        int pos = l_cnt[4 * kClasses + cls];
-        for (int wv = 0; wv < wave; ++wv) pos += l_cnt[wv * kClasses + cls];
+        int pos = l_cnt[4 * kFile + cls];
+        for (int wv = 0; wv < wave; ++wv) pos += l_cnt[wv * kFile + cls];
 #pragma unroll
-        for (int c = 0; c < kClasses; ++c)
+        for (int c = 0; c < kFile; ++c)
             if (cls == c) pos += __popcll(bal[c] & ((1ull << lane) - 1ull));
         uint32_t *lists = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(a.workspace) + ws_list_off((long long)a.B * n));
-        lists[((size_t)q * kClasses + cls) * (size_t)band + pos] = (uint32_t)rid;
+        const int lid = (cls < kClasses) ? q * kClasses + cls : ws_missed_list(q);
+        lists[(size_t)lid * (size_t)band + pos] = (uint32_t)rid;
     }
 }
 
@@ -547,6 +552,16 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
     QueryCtx S;
     float *scratch = lds + (lds_total_floats<MODE>(P) - kScratchFloats);
     int *l_q = reinterpret_cast<int *>(scratch + SC_QUEUE);
+    float *l_btab = scratch + SC_BTAB;
+    if (tid <= Nc) l_btab[tid] = linspace_sym(0.0f, 1.0f, Nc + 1, tid);
+    __syncthreads();
+    // rays without a candidate part first (batches only, enarf_tasks.h): every wave on its own, with a private scratch
+    // slot in the not yet staged MLP section of the LDS (4 x 5.4 KB of 28 KB)
+    static_assert(4 * kSlotWords <= lds_mlp_floats<MODE>(), "scratch slots of the missed-ray pass");
+    const unsigned n_missed = march_missed_rays<SPL>(kernel_render_args(), l_btab, reinterpret_cast<unsigned *>(lds) + wave * kSlotWords,
+                                                     a.multiply_density_with_weight ? (a.uniform_part_weight ? 2 : 1) : 0, lane);
+    if (a.counters && lane == 0 && n_missed) atomicAdd(&a.counters[2], (unsigned long long)n_missed);
+    __syncthreads();
     rq.init(a.workspace, a.ws_epoch, a.B, n, l_q, tid);
     if (tid == 0) rq.pop(0);
     __syncthreads();
@@ -559,14 +574,10 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
     S.mask = a.mask_planes + (size_t)b * a.mask_batch_stride;
     S.H = a.H; S.W = a.W; S.P = P; S.mult_w = a.multiply_density_with_weight ? (a.uniform_part_weight ? 2 : 1) : 0;
     S.clamp_mask = a.clamp_mask; S.uniform_w = a.uniform_part_weight ? 1.0f / (float)P : 0.0f;
-    float *l_btab = scratch + SC_BTAB;
     int *l_cand = reinterpret_cast<int *>(scratch + SC_CAND) + wave * 32;
     float *l_ch = scratch + SC_CH, *l_cwmax = scratch + SC_CWMAX, *l_fh = scratch + SC_FH, *l_fwmax = scratch + SC_FWMAX;
     uint32_t *l_cbits = reinterpret_cast<uint32_t *>(scratch + SC_CBITS);
     uint32_t *l_fbits = reinterpret_cast<uint32_t *>(scratch + SC_FBITS);
-    if (tid <= Nc) l_btab[tid] = linspace_sym(0.0f, 1.0f, Nc + 1, tid);
-    __syncthreads();
-
     unsigned n_pairs = 0, n_tiles = 0, n_rays = 0, n_rounds = 0, n_skipped = 0;
     int qslot = 0;
     const QueryDbg nodbg{nullptr, nullptr, 0, 0};
