@@ -578,6 +578,8 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
     float *l_ch = scratch + SC_CH, *l_cwmax = scratch + SC_CWMAX, *l_fh = scratch + SC_FH, *l_fwmax = scratch + SC_FWMAX;
     uint32_t *l_cbits = reinterpret_cast<uint32_t *>(scratch + SC_CBITS);
     uint32_t *l_fbits = reinterpret_cast<uint32_t *>(scratch + SC_FBITS);
+    __syncthreads();                          // the staged image context is complete before any wave starts a tile
+
     unsigned n_pairs = 0, n_tiles = 0, n_rays = 0, n_rounds = 0, n_skipped = 0;
     int qslot = 0;
     const QueryDbg nodbg{nullptr, nullptr, 0, 0};
