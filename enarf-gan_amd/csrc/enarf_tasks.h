@@ -616,8 +616,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void march_kernel(const enarf_rend
     const RenderArgsK ak = kernel_render_args();
     // rays without a candidate part first (batches only): as many waves as private scratch slots fit into the not yet
     // staged MLP section of the LDS
-    if (wave < lds_mlp_floats<MODE>() / kSlotWords)
-        C.rays += march_missed_rays<SPL>(ak, M.btab, reinterpret_cast<unsigned *>(lds) + wave * kSlotWords, S.mult_w, lane);
+    if (wave < lds_mlp_floats<MODE>() / kSlotWords) {
+        const unsigned n_missed = march_missed_rays<SPL>(ak, M.btab, reinterpret_cast<unsigned *>(lds) + wave * kSlotWords, S.mult_w, lane);
+        if (a.counters && lane == 0 && n_missed) atomicAdd(&a.counters[2], (unsigned long long)n_missed);   // (a workgroup without a first ray returns below)
+    }
     __syncthreads();
     // the first ray decides which image's context the WHOLE workgroup stages (one wave alone takes ~40 us for the 29 KB)
     if (wave == 0) {
