@@ -412,6 +412,26 @@ __device__ __forceinline__ void ray_tile_task(const enarf_render_args &a, const 
 // a private scratch slot, so the waves of a workgroup clear their band's list of missed rays independently before the
 // march proper starts (as ordinary rays they cost 22 % of an 8-frame launch: three barriers each for nothing).
 // `scratch`: kSlotWords words of LDS private to the calling wave. Returns the rays done (wave-uniform).
+// What ray_composite_stage writes when every head and validity bit is zero: T = 1, every weight 1 - e^-0 = +0, every sum
+// +0 - the same bits, without the scans. (Debug runs take the general stage: it also fills the taps.)
+template <int SPL>
+__device__ __forceinline__ void missed_ray_outputs(RenderArgsK a, const unsigned *sw, int lane) {
+    const int Nf = a->Nf, n = a->n;
+    const RayRec rec = *reinterpret_cast<const RayRec *>(sw + SL_REC);
+    const uint32_t rid = sw[SL_RID];
+    const int b = (int)(rid / (uint32_t)n), ray = (int)(rid - (uint32_t)b * (uint32_t)n);
+    const float *l_bins = reinterpret_cast<const float *>(sw + SL_BINS);
+    if (lane < 3) a->color[((size_t)b * 3 + lane) * n + ray] = 0.0f;
+    if (lane == 3) a->mask[(size_t)b * n + ray] = 0.0f;
+    if (lane == 4) a->disparity[(size_t)b * n + ray] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < SPL; ++s) {
+        const int e = 64 * s + lane;
+        if (a->fine_weights && e < Nf - 1) a->fine_weights[((size_t)b * n + ray) * (Nf - 1) + e] = 0.0f;
+        if (a->fine_depth && e < Nf) a->fine_depth[((size_t)b * n + ray) * Nf + e] = exact_lerp(rec.dmin, rec.dmax, l_bins[e]);
+    }
+}
+
 template <int SPL>
 __device__ __forceinline__ unsigned march_missed_rays(RenderArgsK ak, const float *l_btab, unsigned *scratch, int mult_w, int lane) {
     const int B = ak->B, n = ak->n;
@@ -442,7 +462,8 @@ __device__ __forceinline__ unsigned march_missed_rays(RenderArgsK ak, const floa
                 *reinterpret_cast<RayRec *>(scratch + SL_REC) = recs[rid];
             }
             ray_sample_stage<SPL>(ak, l_btab, scratch, mult_w, lane);
-            ray_composite_stage<SPL>(ak, scratch, mult_w, lane);
+            if (ak->dbg_fine_density) ray_composite_stage<SPL>(ak, scratch, mult_w, lane);
+            else missed_ray_outputs<SPL>(ak, scratch, lane);
             done += 1;
         }
     }
@@ -616,10 +637,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void march_kernel(const enarf_rend
     const RenderArgsK ak = kernel_render_args();
     // rays without a candidate part first (batches only): as many waves as private scratch slots fit into the not yet
     // staged MLP section of the LDS
-    if (wave < lds_mlp_floats<MODE>() / kSlotWords) {
-        const unsigned n_missed = march_missed_rays<SPL>(ak, M.btab, reinterpret_cast<unsigned *>(lds) + wave * kSlotWords, S.mult_w, lane);
-        if (a.counters && lane == 0 && n_missed) atomicAdd(&a.counters[2], (unsigned long long)n_missed);   // (a workgroup without a first ray returns below)
-    }
+    if (wave < lds_mlp_floats<MODE>() / kSlotWords)
+        C.rays += march_missed_rays<SPL>(ak, M.btab, reinterpret_cast<unsigned *>(lds) + wave * kSlotWords, S.mult_w, lane);
     __syncthreads();
     // the first ray decides which image's context the WHOLE workgroup stages (one wave alone takes ~40 us for the 29 KB)
     if (wave == 0) {
@@ -633,7 +652,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void march_kernel(const enarf_rend
     }
     __syncthreads();
     const int first = (int)M.sh[SH_FIRST];
-    if (first < 0) return;                         // uniform: every queue was drained before this workgroup got a ray
+    if (first < 0) {                               // uniform: every queue was drained before this workgroup got a ray
+        if (a.counters && lane == 0 && C.rays) atomicAdd(&a.counters[2], (unsigned long long)C.rays);     // its missed rays
+        return;
+    }
     {
         const int b0 = (int)((unsigned)first / (uint32_t)a.n);
         QueryCtx tmp;

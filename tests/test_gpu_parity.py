@@ -561,6 +561,11 @@ def test_both_march_kernels_give_the_same_bits(ops, S, B, Nc, Nf, n0, nr):
             assert torch.equal(a.taps["bins"], other.taps["bins"]), kw
             assert torch.equal(a.counters[:5], other.counters[:5]), (kw, a.counters, other.counters)
         assert int(_cpu(a.counters)[7]) == 0 and int(_cpu(b.counters)[7]) == 0        # no watchdog exit
+        if B > 1:        # rays that miss every cube take a short cut in production runs and the general stages in debug runs
+            dbg = ds.render(coord, Nc, Nf, None, count=True, debug=True, march="ray", **kw)
+            assert int((_cpu(dbg.taps["ray_validity"]) == 0).sum()) > 20
+            for name in ("color", "mask", "disparity", "fine_weights", "fine_depth"):
+                assert torch.equal(getattr(a, name), getattr(dbg, name)), (name, kw, "debug vs production")
     assert nr < 100 or float(a.mask.max()) > 0.05
     with pytest.raises(KeyError):
         ds.render(coord, Nc, Nf, None, march="fastest")
