@@ -92,6 +92,23 @@ def test_tap_offsets_stay_inside_the_plane(tmp_path):
     assert int(r.stdout.split()[1]) > 100000
 
 
+def test_build_tracks_every_included_header():
+    """enarf_gan_amd.build rebuilds an object when any header its source includes (directly or through another header)
+    changed: a header missing from the dependency list leaves the product library stale after a header-only edit."""
+    import re
+    from enarf_gan_amd import build as B
+    tracked = {os.path.basename(h) for h in B.HEADERS}
+    seen, todo = set(), list(B.SOURCES)
+    while todo:
+        f = todo.pop()
+        path = os.path.join(B.CSRC, f) if os.path.exists(os.path.join(B.CSRC, f)) else os.path.join(ROOT, "include", f)
+        for inc in re.findall(r'#include\s+"([^"]+)"', open(path).read()):
+            if inc not in seen:
+                seen.add(inc)
+                todo.append(inc)
+    assert seen and seen <= tracked, seen - tracked
+
+
 def test_built_library_has_only_in_place_mfma_chains():
     """ISA lint of the built library (tools/check_mfma_chains.py): a chained MFMA whose vDst differs from its SrcC, or
     partially overlaps it, is issued by the compiler without a wait state and does not reliably see its predecessor's

@@ -19,7 +19,8 @@ for rep in range(3):
         poison = [torch.full((B * 3 * nr * 4 + (i + 1) * 4096,), float("nan"), device="cuda") for i in range(6)]   # freed: the outputs land on NaNs
         del poison
         o = ds.render(coord, Nc, Nf, None, count=True, return_bins=True, march=m, seed=5, debug=(os.environ.get("DEBUG", "1") == "1"))
-        print("   nan in outputs:", [int(torch.isnan(getattr(o, nm)).sum()) for nm in ("color", "mask", "disparity", "fine_weights", "fine_depth")])
+        print("   nan in outputs:", [int(torch.isnan(getattr(o, nm)).sum()) for nm in ("color", "mask", "disparity", "fine_weights", "fine_depth")],
+              "rays with all-zero fine_depth:", int((o.fine_depth.abs().sum(-1) == 0).sum()))
         if rep == 0 and m == "ray":
             first_taps = {k: v.clone() for k, v in o.taps.items() if torch.is_tensor(v)}
         runs[(m, rep)] = o
