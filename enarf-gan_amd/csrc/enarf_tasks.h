@@ -639,9 +639,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void march_kernel(const enarf_rend
     // staged MLP section of the LDS
     if (wave < lds_mlp_floats<MODE>() / kSlotWords)
         C.rays += march_missed_rays<SPL>(ak, M.btab, reinterpret_cast<unsigned *>(lds) + wave * kSlotWords, S.mult_w, lane);
-#ifdef ENARF_DIAG_COUNT_SPLIT
-    if (a.counters && lane == 0) atomicAdd(&a.counters[5], (unsigned long long)C.rays);
-#endif
     __syncthreads();
     // the first ray decides which image's context the WHOLE workgroup stages (one wave alone takes ~40 us for the 29 KB)
     if (wave == 0) {
@@ -657,9 +654,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void march_kernel(const enarf_rend
     const int first = (int)M.sh[SH_FIRST];
     if (first < 0) {                               // uniform: every queue was drained before this workgroup got a ray
         if (a.counters && lane == 0 && C.rays) atomicAdd(&a.counters[2], (unsigned long long)C.rays);     // its missed rays
-#ifdef ENARF_DIAG_COUNT_SPLIT
-        if (a.counters && lane == 0) atomicAdd(&a.counters[6], 1ull);
-#endif
         return;
     }
     {
