@@ -1030,8 +1030,8 @@ int device_cus() {
 //   march_kernel    one workgroup (12 waves) per CU, several rays in flight, 16-sample tiles claimed as tasks.
 // ENARF_TASK_MARCH: 0 / 1 force one of them (A/B builds); 2 (product) picks by shape, from measurements on MI355X
 // (DESIGN.md 3.1): the task march wins where a pass has more tiles than a 4-wave workgroup has waves (Nc or Nf > 64:
-// 0.32 vs 0.36 ms at 128^2, 72 + 96), ties at 48 + 64 (0.235 vs 0.229) and loses on batches, where every change of
-// image drains its pipeline (8 frames: 2.60 vs 1.82 ms).
+// 0.31 vs 0.36 ms at 128^2, 72 + 96), ties at 48 + 64 (0.225 vs 0.225) and loses on batches, where every change of
+// image drains its pipeline (8 frames: 2.60 vs 1.79 ms).
 #ifndef ENARF_TASK_MARCH
 #define ENARF_TASK_MARCH 2
 #endif

@@ -1,4 +1,6 @@
-// enarf_tasks.h - the ray march as a pool of tile tasks (round 2; replaces the barrier-structured workgroup-per-ray march).
+// enarf_tasks.h - the ray march as a pool of tile tasks (round 2; the second march kernel beside the barrier-structured
+// workgroup-per-ray render_kernel of enarf_render.hip - same stages, same bits; enarf_render_args.march picks one), the
+// two serial ray stages both kernels share, and the pass over the rays that miss every cube.
 //
 // One persistent workgroup of NW wavefronts per CU keeps R rays in flight, each in an LDS "slot". A ray's life is a chain
 //     pop -> C coarse tiles -> S2 (weights, importance samples) -> F fine tiles -> S4 (compositing, outputs) -> pop ...
