@@ -73,6 +73,7 @@ def parse():
                     help="device spin-up during set-up, before the W warm-up steps (not part of W or K)")
     ap.add_argument("--no-p24", action="store_true", help="skip the extra timed pass with origin_location center+head (P = 24)")
     ap.add_argument("--no-f32", action="store_true", help="skip the extra timed pass with the exact fp32 MLP arithmetic")
+    ap.add_argument("--no-two-streams", action="store_true", help="skip the extra timed pass over two HIP streams")
     ap.add_argument("--allow-variant", action="store_true", help="measurement only: permit --variant")
     ap.add_argument("--variant", default=None, help="another build of the same ABI (tools/build_variant.sh); needs --allow-variant")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -334,6 +335,27 @@ def main():
         dt = timed_variant(lambda: bound_step(99, mode="f32").run())
         f32_mode = {"workload": "the same step with the exact fp32 MLP arithmetic (v_mfma_f32_16x16x4_f32)",
                     "value": B * n * args.steps / dt, "unit": "rays/s", "ms_per_step": dt / args.steps * 1e3}
+    two_streams = None
+    if extras and n_streams == 1 and not args.no_two_streams:
+        # the same K steps alternating over two HIP streams with private intermediates: the next step's pre-march launch
+        # (serial chains of a few blocks) runs in the tail of the persistent march. Reported beside `value`, which stays
+        # the single-stream number the roofline figures are measured on.
+        s2 = torch.cuda.Stream(dev)
+        f2 = torch.empty_like(feat_cl)
+        ops.triplane_pack(tri, f2)
+        sets.append((f2, torch.empty(B, P, 16, device=dev), torch.empty(B, ops.mlp_pack_bytes(), dtype=torch.uint8, device=dev)))
+        pair = [streams[0], s2]
+        turn = [0]
+
+        def one():
+            k = turn[0] & 1
+            turn[0] += 1
+            with torch.cuda.stream(pair[k]):
+                bound_step(99, k=k).run()
+        torch.cuda.synchronize()
+        dt = timed_variant(one)
+        two_streams = {"workload": "the same steps alternating over two HIP streams (private intermediates per stream)",
+                       "value": B * n * args.steps / dt, "unit": "rays/s", "ms_per_step": dt / args.steps * 1e3}
     p24 = None
     if extras and args.origin == "center_fixed" and not args.no_p24:
         # the same step with the head part added (center+head, P = 24): K timed steps after W warm-up steps, serial
@@ -428,6 +450,8 @@ def main():
         }
         if f32_mode is not None:
             out["f32_mode"] = f32_mode
+        if two_streams is not None:
+            out["two_streams"] = two_streams
         if p24 is not None:
             out["p24"] = p24
         if not args.no_cpu_baseline and world == 1:

@@ -6,7 +6,7 @@ O=gpurun_out/r2m; mkdir -p $O
 rc=0; python -m pytest tests/test_gpu_parity.py tests/test_gpu_configs.py -m gpu -q -x > $O/pytest_full.log 2>&1 || rc=$?
 grep -v amdgpu.ids $O/pytest_full.log | tail -8 | tee $O/pytest.log
 if [ $rc -gt 1 ]; then echo "pytest rc=$rc: stopping"; exit $rc; fi
-B="python bench.py --no-cpu-baseline --no-p24 --no-f32"
+B="python bench.py --no-cpu-baseline --no-p24 --no-f32 --no-two-streams"
 run() { name=$1; shift; $B "$@" 2>&1 | grep -v amdgpu.ids | python tools/exline.py $name; }
 var() { echo "--allow-variant --variant variants/libenarf_$1.so"; }
 {

@@ -7,7 +7,7 @@ rc=0; python -m pytest tests/test_gpu_parity.py tests/test_gpu_configs.py tests/
 grep -v amdgpu.ids $O/pytest_full.log | tail -8 | tee $O/pytest.log
 if [ $rc -gt 1 ]; then echo "pytest rc=$rc: stopping"; exit $rc; fi
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | grep -v amdgpu.ids | tail -2
-B="python bench.py --no-cpu-baseline --no-p24 --no-f32"
+B="python bench.py --no-cpu-baseline --no-p24 --no-f32 --no-two-streams"
 run() { name=$1; shift; $B "$@" 2>&1 | grep -v amdgpu.ids | python tools/exline.py $name; }
 var() { echo "--allow-variant --variant variants/libenarf_$1.so"; }
 {

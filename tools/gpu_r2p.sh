@@ -3,7 +3,7 @@
 set -eo pipefail
 ulimit -c 0
 O=gpurun_out/r2p; mkdir -p $O
-B="python bench.py --no-cpu-baseline --no-p24 --no-f32"
+B="python bench.py --no-cpu-baseline --no-p24 --no-f32 --no-two-streams"
 run() { name=$1; shift; $B "$@" 2>&1 | grep -v amdgpu.ids | python tools/exline.py $name; }
 var() { echo "--allow-variant --variant variants/libenarf_$1.so"; }
 {

@@ -2,7 +2,7 @@
 set -eo pipefail
 ulimit -c 0
 O=gpurun_out/r2q; mkdir -p $O
-B="python bench.py --no-cpu-baseline --no-p24 --no-f32"
+B="python bench.py --no-cpu-baseline --no-p24 --no-f32 --no-two-streams"
 run() { name=$1; shift; $B "$@" 2>&1 | grep -v amdgpu.ids | python tools/exline.py $name; }
 {
 run B8 --steps 60 --batch 8
