@@ -103,6 +103,14 @@ __device__ __forceinline__ void ws_clear_other_header(void *workspace, int epoch
 #ifndef ENARF_IMAGE_BANDS
 #define ENARF_IMAGE_BANDS 1
 #endif
+// rays per set-up block: 256 threads, kSetupLanes lanes per ray (enarf_render.hip ray_setup_block)
+#ifndef ENARF_SETUP_LANES
+#define ENARF_SETUP_LANES 8
+#endif
+constexpr int kSetupLanes = ENARF_SETUP_LANES;
+constexpr int kSetupRays = 256 / kSetupLanes;
+static_assert(kSetupLanes == 4 || kSetupLanes == 8, "set-up lanes per ray");
+__host__ __device__ inline int ws_setup_blocks(int n) { return (n + kSetupRays - 1) / kSetupRays; }
 __host__ __device__ inline long long ws_npad(int n) { return 64ll * ((n + 63) / 64); }
 __host__ __device__ inline long long ws_image_band(int n) {          // rays of one image per band
     return 64ll * ((ws_npad(n) + 64ll * kQueues - 1) / (64ll * kQueues));
@@ -118,9 +126,9 @@ __host__ __device__ inline long long ws_band_size(int B, int n) {     // capacit
 // band of set-up block `blk` of image b
 __host__ __device__ inline int ws_band_of(int B, int n, int b, int blk) {
 #if ENARF_IMAGE_BANDS
-    return (int)(((long long)b * ws_npad(n) + 64ll * blk) / ws_band_size(B, n));
+    return (int)(((long long)b * ws_npad(n) + (long long)kSetupRays * blk) / ws_band_size(B, n));
 #else
-    return (int)((64ll * blk) / ws_image_band(n));
+    return (int)(((long long)kSetupRays * blk) / ws_image_band(n));
 #endif
 }
 __host__ __device__ inline size_t ws_total_bytes(int B, int n) {

@@ -128,6 +128,13 @@ __device__ __forceinline__ void prepare_block(const enarf_prepare_args &a, int l
     }
     const float *z = a.z_rend + (size_t)b * a.style_dim;
     const float mscale = 1.0f / sqrtf((float)a.style_dim);
+    // the layer's conv weights (<= 16 per thread) are fetched before the style chain, not behind its barrier
+    float cw[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int e = tid + 256 * i;
+        cw[i] = (e < cout * cin) ? a.conv_weight[layer][e] : 0.0f;
+    }
     if (tid < cin) {   // EqualLinear: z @ (Wm * scale)^T + b_mod
         const float *wm = a.mod_weight[layer] + (size_t)tid * a.style_dim;
         float acc = 0.0f;
@@ -136,7 +143,11 @@ __device__ __forceinline__ void prepare_block(const enarf_prepare_args &a, int l
     }
     __syncthreads();
     const float cscale = 1.0f / sqrtf((float)cin);
-    for (int e = tid; e < cout * cin; e += 256) s_w[e] = (cscale * a.conv_weight[layer][e]) * s_style[e % cin];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int e = tid + 256 * i;
+        if (e < cout * cin) s_w[e] = (cscale * cw[i]) * s_style[e % cin];
+    }
     __syncthreads();
     if (tid < cout) {   // F.normalize(dim=-1, eps=1e-12)
         float ss = 0.0f;
@@ -301,6 +312,28 @@ __device__ __forceinline__ bool ray_hits_part(const float *F, float dx, float dy
     return t0 <= t1;
 }
 
+// reductions over the G adjacent lanes of one ray (G = 4: the quad; G = 8: two quads, second step by row_half_mirror -
+// after the quad step every lane of a quad holds its quad's value, and lane i of the half row meets lane 7 - i)
+template <int G>
+__device__ __forceinline__ uint32_t group_or(uint32_t v) {
+    v |= (uint32_t)quad_perm_i<0xB1>((int)v);
+    v |= (uint32_t)quad_perm_i<0x4E>((int)v);
+    if (G == 8) v |= (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xF, 0xF, true);     // row_half_mirror
+    return v;
+}
+template <int G>
+__device__ __forceinline__ float group_min(float v) {
+    v = fminf(v, quad_perm_f<0xB1>(v)); v = fminf(v, quad_perm_f<0x4E>(v));
+    if (G == 8) v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x141, 0xF, 0xF, true)));
+    return v;
+}
+template <int G>
+__device__ __forceinline__ float group_max(float v) {
+    v = fmaxf(v, quad_perm_f<0xB1>(v)); v = fmaxf(v, quad_perm_f<0x4E>(v));
+    if (G == 8) v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x141, 0xF, 0xF, true)));
+    return v;
+}
+
 // =================================================================================================
 // ray set-up pre-pass: depth range, candidate parts and the compacted list of rays to march
 // =================================================================================================
@@ -321,8 +354,17 @@ __device__ __forceinline__ void ray_setup_block(const enarf_render_args &a, cons
     float *l_dtab = smem + ENARF_MAX_PARTS * kLdsPartStride;
     float *l_red = l_dtab + 32;
     int *l_cnt = reinterpret_cast<int *>(l_red + 12);
-    const int lane = tid & 63, wave = tid >> 6, g = tid & 3;
+    constexpr int G = kSetupLanes;              // lanes per ray: they split the parts and the 32 range-test depths
+    const int lane = tid & 63, wave = tid >> 6, g = tid & (G - 1);
     const int P = a.P, n = a.n, Nf = a.Nf;
+    // the ray's own inputs first: their round trip overlaps the part-frame and near / far chains below
+    const int ray = blk * kSetupRays + tid / G;
+    const bool in_range = ray < n;
+    const int rc = in_range ? ray : n - 1;
+    const float *coord = a.image_coord + (size_t)b * 3 * n;
+    const float *Ki = a.inv_intrinsics + (size_t)b * 9;
+    const float u = coord[rc], v = coord[n + rc], w = coord[2 * n + rc];
+    const float k0 = Ki[0], k1 = Ki[1], k2 = Ki[2], k3 = Ki[3], k4 = Ki[4], k5 = Ki[5], k6 = Ki[6], k7 = Ki[7], k8 = Ki[8];
     if constexpr (RAW) {
         if (tid < P) {
             float fr[16];
@@ -359,29 +401,23 @@ __device__ __forceinline__ void ray_setup_block(const enarf_render_args &a, cons
     if (tid < 32) l_dtab[tid] = linspace_sym(near_p, far_p, 32, tid);
     __syncthreads();
 
-    const int ray = blk * 64 + (tid >> 2);
-    const bool in_range = ray < n;
-    const int rc = in_range ? ray : n - 1;
-    const float *coord = a.image_coord + (size_t)b * 3 * n;
-    const float *Ki = a.inv_intrinsics + (size_t)b * 9;
-    const float u = coord[rc], v = coord[n + rc], w = coord[2 * n + rc];
-    const float dx = exact_dot3(Ki[0], u, Ki[1], v, Ki[2], w);
-    const float dy = exact_dot3(Ki[3], u, Ki[4], v, Ki[5], w);
-    const float dz = exact_dot3(Ki[6], u, Ki[7], v, Ki[8], w);
+    const float dx = exact_dot3(k0, u, k1, v, k2, w);
+    const float dy = exact_dot3(k3, u, k4, v, k5, w);
+    const float dz = exact_dot3(k6, u, k7, v, k8, w);
 
-    // parts the ray can touch between near and far (conservative), split over the quad
+    // parts the ray can touch between near and far (conservative), split over the ray's lanes
     uint32_t mine = 0;
-    for (int k = g; k < P; k += 4)
+    for (int k = g; k < P; k += G)
         if (ray_hits_part(l_parts + k * kLdsPartStride, dx, dy, dz, near_p, far_p)) mine |= 1u << k;
-    uint32_t cand_all = mine | (uint32_t)quad_perm_i<0xB1>((int)mine);
-    cand_all |= (uint32_t)quad_perm_i<0x4E>((int)cand_all);
+    const uint32_t cand_all = group_or<G>(mine);
 
-    // exact range test: this lane's 8 of the 32 depths x candidate parts; part outer (its frame is read from LDS
-    // once), depths inner; bit d of `in8` = some part contains depth g*8 + d
-    float qx[8], qy[8], qz[8];
+    // exact range test: this lane's D of the 32 depths x candidate parts; part outer (its frame is read from LDS
+    // once), depths inner; bit d of `in8` = some part contains depth g*D + d
+    constexpr int D = 32 / G;
+    float qx[D], qy[D], qz[D];
 #pragma unroll
-    for (int d = 0; d < 8; ++d) {
-        const float ds = l_dtab[g * 8 + d];
+    for (int d = 0; d < D; ++d) {
+        const float ds = l_dtab[g * D + d];
         qx[d] = exact_mul(dx, ds); qy[d] = exact_mul(dy, ds); qz[d] = exact_mul(dz, ds);
     }
     uint32_t in8 = 0;
@@ -396,7 +432,7 @@ __device__ __forceinline__ void ray_setup_block(const enarf_render_args &a, cons
 #pragma unroll
             for (int i = 0; i < 4; ++i) { F[i] = f0[i]; F[4 + i] = f1[i]; F[8 + i] = f2[i]; }
 #pragma unroll
-            for (int d = 0; d < 8; ++d) {
+            for (int d = 0; d < D; ++d) {
                 float lx, ly, lz;
                 exact_local(F, qx[d], qy[d], qz[d], lx, ly, lz);
                 if (in_unit_cube_incl(lx, ly, lz)) in8 |= 1u << d;
@@ -405,15 +441,15 @@ __device__ __forceinline__ void ray_setup_block(const enarf_render_args &a, cons
     }
     float mn = 1.0e3f, mx = -1.0e3f;
 #pragma unroll
-    for (int d = 0; d < 8; ++d) {
+    for (int d = 0; d < D; ++d) {
         if ((in8 >> d) & 1u) {
-            const float ds = l_dtab[g * 8 + d];
+            const float ds = l_dtab[g * D + d];
             mn = fminf(mn, ds);
             mx = fmaxf(mx, ds);
         }
     }
-    mn = fminf(mn, quad_perm_f<0xB1>(mn)); mn = fminf(mn, quad_perm_f<0x4E>(mn));
-    mx = fmaxf(mx, quad_perm_f<0xB1>(mx)); mx = fmaxf(mx, quad_perm_f<0x4E>(mx));
+    mn = group_min<G>(mn);
+    mx = group_max<G>(mx);
     const bool ray_valid = (mn != 1.0e3f);
     float dmin = ray_valid ? mn : near_p;
     const float dmax = (mx != -1.0e3f) ? mx : far_p;
@@ -422,10 +458,9 @@ __device__ __forceinline__ void ray_setup_block(const enarf_render_args &a, cons
 
     // parts over the marched segment only
     uint32_t mine2 = 0;
-    for (int k = g; k < P; k += 4)
+    for (int k = g; k < P; k += G)
         if (((cand_all >> k) & 1u) && ray_hits_part(l_parts + k * kLdsPartStride, dx, dy, dz, dmin, dmax)) mine2 |= 1u << k;
-    uint32_t cand = mine2 | (uint32_t)quad_perm_i<0xB1>((int)mine2);
-    cand |= (uint32_t)quad_perm_i<0x4E>((int)cand);
+    const uint32_t cand = group_or<G>(mine2);
 
     const size_t rid = (size_t)b * n + rc;
     if (in_range && g == 0) {
@@ -440,8 +475,8 @@ __device__ __forceinline__ void ray_setup_block(const enarf_render_args &a, cons
     if (in_range && !live && a.color) {   // dropped ray: zeros (rendering.py:337-350); the backward passes no outputs
         if (g < 3) a.color[((size_t)b * 3 + g) * n + ray] = 0.0f;
         if (g == 3) { a.mask[rid] = 0.0f; a.disparity[rid] = 0.0f; }
-        if (a.fine_weights) for (int i = g; i < Nf - 1; i += 4) a.fine_weights[rid * (Nf - 1) + i] = 0.0f;
-        if (a.fine_depth) for (int i = g; i < Nf; i += 4) a.fine_depth[rid * Nf + i] = 0.0f;
+        if (a.fine_weights) for (int i = g; i < Nf - 1; i += G) a.fine_weights[rid * (Nf - 1) + i] = 0.0f;
+        if (a.fine_depth) for (int i = g; i < Nf; i += G) a.fine_depth[rid * Nf + i] = 0.0f;
     }
     // file the block's live rays, in ray order, under (band, cost class) - see RayQueue; live rays without a candidate
     // part (batches only: a single image drops them) go to the band's list of missed rays
@@ -1009,7 +1044,7 @@ int launch_ray_setup(const enarf_render_args &a, hipStream_t st) {
         hipError_t e = hipMemsetAsync(a.workspace, 0, 2 * kWsHeaderBytes, st);
         if (e != hipSuccess) return host::fail((int)e, "ray set-up: hipMemsetAsync(workspace) failed: %s", hipGetErrorString(e));
     }
-    const int bpi = (a.n + 63) / 64;
+    const int bpi = ws_setup_blocks(a.n);
     hipLaunchKernelGGL(ray_setup_kernel, dim3((unsigned)(bpi * a.B)), dim3(256), 0, st, a, bpi);
     return host::check_launch("ray set-up");
 }
@@ -1154,7 +1189,7 @@ extern "C" int enarf_render_step_fwd(const enarf_prepare_args *prep, const float
     q.H = r.H; q.W = r.W;
     q.n_pack = tri_nchw ? ((r.W + 63) / 64) * r.H * tri_B * 3 : 0;
     q.n_prep = 3 * p.B;
-    q.bpi = (r.n + 63) / 64;
+    q.bpi = ws_setup_blocks(r.n);
     const long long blocks = (long long)q.n_pack + q.n_prep + (long long)q.bpi * r.B;
     if (blocks > 0x7FFFFFFFll) return host::fail(ENARF_ERR_UNSUPPORTED, "enarf_render_step_fwd: too many blocks");
     hipLaunchKernelGGL(pre_march_kernel, dim3((unsigned)blocks), dim3(256), 0, st, q);
