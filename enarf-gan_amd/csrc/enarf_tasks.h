@@ -191,6 +191,29 @@ __device__ __forceinline__ void draw_sorted_uniforms(RenderArgsK a, uint32_t rid
     for (int s = 0; s < SPL; ++s) usort[s] = fminf(esum[s] / etot, 0.99999994f);
 }
 
+// Nf sorted importance samples of ray `rid` from the (inclusive, unnormalised) cdf of its Nc smoothed coarse weights
+template <int SPL>
+__device__ __forceinline__ void bins_from_cdf(RenderArgsK a, uint32_t rid, int Nc, int Nf, const float cdf[SPL], int lane, float bin[SPL]) {
+    float usort[SPL];
+    draw_sorted_uniforms<SPL>(a, rid, Nf, lane, usort);
+    const float total = wv_get<SPL>(cdf, Nc - 1);
+#pragma unroll
+    for (int s = 0; s < SPL; ++s) {
+        const float target = usort[s] * total;
+        int lo = 0, hi = Nc - 1;   // smallest i with cdf[i] > target
+#pragma unroll
+        for (int it = 0; it < 5 + SPL; ++it) {
+            const int mid = (lo + hi) >> 1;
+            const float c = wv_get<SPL>(cdf, mid);
+            if (lo < hi) { if (c > target) hi = mid; else lo = mid + 1; }
+        }
+        const float c_hi = wv_get<SPL>(cdf, lo), c_lo = wv_get<SPL>(cdf, max(lo - 1, 0));
+        const float below = (lo > 0) ? c_lo : 0.0f;
+        const float frac = fminf(fmaxf((target - below) / (c_hi - below), 0.0f), 0.99999994f);
+        bin[s] = (64 * s + lane < Nf) ? ((float)lo + frac) / (float)Nc : 3.0e38f;
+    }
+}
+
 // S2 of one ray (ONE wave, element e = 64 s + lane): coarse weights (rendering.py:180-184), smoothing (:187-190), the
 // importance samples (:192-197) and the early-termination flags of the fine tiles; everything from / to the slot
 template <int SPL>
@@ -242,28 +265,11 @@ __device__ __noinline__ void ray_sample_stage(RenderArgsK a, const float *l_btab
         // Importance samples = Nf iid draws from the piecewise-constant pdf, sorted (rendering.py:192-197): sorted uniforms
         // pushed through the inverse CDF (monotone, so the bins come out sorted) - bin index by binary search, position
         // inside the bin by the leftover: the same law as multinomial + U / Nc + sort.
-        float usort[SPL];
-        draw_sorted_uniforms<SPL>(a, rid, Nf, lane, usort);
         float cdf[SPL];
 #pragma unroll
         for (int s = 0; s < SPL; ++s) cdf[s] = ws[s];
         wv_scan_incl<SPL>(cdf, lane);
-        const float total = wv_get<SPL>(cdf, Nc - 1);
-#pragma unroll
-        for (int s = 0; s < SPL; ++s) {
-            const float target = usort[s] * total;
-            int lo = 0, hi = Nc - 1;   // smallest i with cdf[i] > target
-#pragma unroll
-            for (int it = 0; it < 5 + SPL; ++it) {
-                const int mid = (lo + hi) >> 1;
-                const float c = wv_get<SPL>(cdf, mid);
-                if (lo < hi) { if (c > target) hi = mid; else lo = mid + 1; }
-            }
-            const float c_hi = wv_get<SPL>(cdf, lo), c_lo = wv_get<SPL>(cdf, max(lo - 1, 0));
-            const float below = (lo > 0) ? c_lo : 0.0f;
-            const float frac = fminf(fmaxf((target - below) / (c_hi - below), 0.0f), 0.99999994f);
-            bin[s] = (64 * s + lane < Nf) ? ((float)lo + frac) / (float)Nc : 3.0e38f;
-        }
+        bins_from_cdf<SPL>(a, rid, Nc, Nf, cdf, lane, bin);
     }
 #pragma unroll
     for (int s = 0; s < SPL; ++s) {
@@ -414,35 +420,48 @@ __device__ __forceinline__ void ray_tile_task(const enarf_render_args &a, const 
 // a private scratch slot, so the waves of a workgroup clear their band's list of missed rays independently before the
 // march proper starts (as ordinary rays they cost 22 % of an 8-frame launch: three barriers each for nothing).
 // `scratch`: kSlotWords words of LDS private to the calling wave. Returns the rays done (wave-uniform).
-// What ray_composite_stage writes when every head and validity bit is zero: T = 1, every weight 1 - e^-0 = +0, every sum
-// +0 - the same bits, without the scans. (Debug runs take the general stage: it also fills the taps.)
+// A ray without a valid sample, in production runs (no debug taps): its coarse weights are all +0, so the smoothed weights
+// are 0.01 in every bin ((0 + 0) / 2 + 0.01 exactly as ray_sample_stage forms them) and their cdf is the same for every such
+// ray - scanned once per wave by the caller; what ray_composite_stage would write is T = 1, every weight 1 - e^-0 = +0,
+// every sum +0. Same bits as the two general stages, without their scans.
 template <int SPL>
-__device__ __forceinline__ void missed_ray_outputs(RenderArgsK a, const unsigned *sw, int lane) {
-    const int Nf = a->Nf, n = a->n;
-    const RayRec rec = *reinterpret_cast<const RayRec *>(sw + SL_REC);
-    const uint32_t rid = sw[SL_RID];
+__device__ __forceinline__ void missed_ray_short_cut(RenderArgsK a, uint32_t rid, const RayRec &rec, const float cdf[SPL], int lane) {
+    const int Nc = a->Nc, Nf = a->Nf, n = a->n;
     const int b = (int)(rid / (uint32_t)n), ray = (int)(rid - (uint32_t)b * (uint32_t)n);
-    const float *l_bins = reinterpret_cast<const float *>(sw + SL_BINS);
+    float bin[SPL];
+    if (a->bins) {
+#pragma unroll
+        for (int s = 0; s < SPL; ++s) bin[s] = a->bins[((size_t)b * n + ray) * Nf + min(64 * s + lane, Nf - 1)];
+    } else {
+        bins_from_cdf<SPL>(a, rid, Nc, Nf, cdf, lane, bin);
+    }
     if (lane < 3) a->color[((size_t)b * 3 + lane) * n + ray] = 0.0f;
     if (lane == 3) a->mask[(size_t)b * n + ray] = 0.0f;
     if (lane == 4) a->disparity[(size_t)b * n + ray] = 0.0f;
 #pragma unroll
     for (int s = 0; s < SPL; ++s) {
         const int e = 64 * s + lane;
+        if (a->dbg_bins && e < Nf) a->dbg_bins[((size_t)b * n + ray) * Nf + e] = bin[s];
         if (a->fine_weights && e < Nf - 1) a->fine_weights[((size_t)b * n + ray) * (Nf - 1) + e] = 0.0f;
-        if (a->fine_depth && e < Nf) a->fine_depth[((size_t)b * n + ray) * Nf + e] = exact_lerp(rec.dmin, rec.dmax, l_bins[e]);
+        if (a->fine_depth && e < Nf) a->fine_depth[((size_t)b * n + ray) * Nf + e] = exact_lerp(rec.dmin, rec.dmax, bin[s]);
     }
 }
 
 template <int SPL>
 __device__ __forceinline__ unsigned march_missed_rays(RenderArgsK ak, const float *l_btab, unsigned *scratch, int mult_w, int lane) {
-    const int B = ak->B, n = ak->n;
+    const int B = ak->B, n = ak->n, Nc = ak->Nc;
     const char *ws = reinterpret_cast<const char *>(ak->workspace);
     unsigned int *wsh = reinterpret_cast<unsigned int *>(const_cast<char *>(ws) + ws_header_off(ak->ws_epoch));
     const uint32_t *lists = reinterpret_cast<const uint32_t *>(ws + ws_list_off((long long)B * n));
     const RayRec *recs = reinterpret_cast<const RayRec *>(ws + ws_records_off());
     const long long band = ws_band_size(B, n);
     const int home = xcc_id() & (kQueues - 1);
+    // debug runs (taps wanted) and the diagnostic fixed-grid build take the two general stages on a zeroed scratch slot
+    const bool general = ak->dbg_fine_density || ak->dbg_coarse_density || (ENARF_DIAG_ABLATE & 8);
+    float cdf[SPL];
+#pragma unroll
+    for (int s = 0; s < SPL; ++s) cdf[s] = (64 * s + lane < Nc) ? (0.0f + 0.0f) / 2.0f + 0.01f : 0.0f;
+    wv_scan_incl<SPL>(cdf, lane);
     unsigned done = 0;
     bool zeroed = false;
     for (int t = 0; t < kQueues; ++t) {
@@ -454,18 +473,21 @@ __device__ __forceinline__ unsigned march_missed_rays(RenderArgsK ak, const floa
             if (lane == 0) j = atomicAdd(wsh + kWsHeadsOff + l * kWsHeadStride, 1u);
             j = (unsigned)__builtin_amdgcn_readfirstlane((int)j);
             if (j >= len) break;
-            if (!zeroed) {       // heads and validity bits of a ray without a valid sample: all zero, for every ray alike
-                for (int i = lane; i < kSlotWords; i += 64) scratch[i] = 0u;
-                zeroed = true;
+            const uint32_t rid = (uint32_t)__builtin_amdgcn_readfirstlane((int)lists[(size_t)l * (size_t)band + j]);
+            if (general) {
+                if (!zeroed) {   // heads and validity bits of a ray without a valid sample: all zero, for every ray alike
+                    for (int i = lane; i < kSlotWords; i += 64) scratch[i] = 0u;
+                    zeroed = true;
+                }
+                if (lane == 0) {
+                    scratch[SL_RID] = rid;
+                    *reinterpret_cast<RayRec *>(scratch + SL_REC) = recs[rid];
+                }
+                ray_sample_stage<SPL>(ak, l_btab, scratch, mult_w, lane);
+                ray_composite_stage<SPL>(ak, scratch, mult_w, lane);
+            } else {
+                missed_ray_short_cut<SPL>(ak, rid, recs[rid], cdf, lane);
             }
-            const uint32_t rid = lists[(size_t)l * (size_t)band + j];
-            if (lane == 0) {
-                scratch[SL_RID] = rid;
-                *reinterpret_cast<RayRec *>(scratch + SL_REC) = recs[rid];
-            }
-            ray_sample_stage<SPL>(ak, l_btab, scratch, mult_w, lane);
-            if (ak->dbg_fine_density) ray_composite_stage<SPL>(ak, scratch, mult_w, lane);
-            else missed_ray_outputs<SPL>(ak, scratch, lane);
             done += 1;
         }
     }

@@ -566,6 +566,7 @@ def test_both_march_kernels_give_the_same_bits(ops, S, B, Nc, Nf, n0, nr):
             assert int((_cpu(dbg.taps["ray_validity"]) == 0).sum()) > 20
             for name in ("color", "mask", "disparity", "fine_weights", "fine_depth"):
                 assert torch.equal(getattr(a, name), getattr(dbg, name)), (name, kw, "debug vs production")
+            assert torch.equal(a.taps["bins"], dbg.taps["bins"]), (kw, "bins: debug vs production")
     assert nr < 100 or float(a.mask.max()) > 0.05
     with pytest.raises(KeyError):
         ds.render(coord, Nc, Nf, None, march="fastest")
