@@ -447,6 +447,10 @@ __device__ __forceinline__ void missed_ray_short_cut(RenderArgsK a, uint32_t rid
     }
 }
 
+#ifndef ENARF_MISSED_CHUNK
+#define ENARF_MISSED_CHUNK 8
+#endif
+constexpr int kMissedChunk = ENARF_MISSED_CHUNK;
 template <int SPL>
 __device__ __forceinline__ unsigned march_missed_rays(RenderArgsK ak, const float *l_btab, unsigned *scratch, int mult_w, int lane) {
     const int B = ak->B, n = ak->n, Nc = ak->Nc;
@@ -469,26 +473,31 @@ __device__ __forceinline__ unsigned march_missed_rays(RenderArgsK ak, const floa
         const unsigned len = wsh[kWsCountsOff + l];                 // final: written by the set-up pass of an earlier launch
         if (len == 0u) continue;
         while (true) {
-            unsigned j = 0;
-            if (lane == 0) j = atomicAdd(wsh + kWsHeadsOff + l * kWsHeadStride, 1u);
-            j = (unsigned)__builtin_amdgcn_readfirstlane((int)j);
-            if (j >= len) break;
-            const uint32_t rid = (uint32_t)__builtin_amdgcn_readfirstlane((int)lists[(size_t)l * (size_t)band + j]);
-            if (general) {
-                if (!zeroed) {   // heads and validity bits of a ray without a valid sample: all zero, for every ray alike
-                    for (int i = lane; i < kSlotWords; i += 64) scratch[i] = 0u;
-                    zeroed = true;
+            // a chunk of the list per atomic: tens of thousands of equally cheap rays behind eight queue heads would
+            // otherwise spend their time queueing at those eight cache lines
+            unsigned j0 = 0;
+            if (lane == 0) j0 = atomicAdd(wsh + kWsHeadsOff + l * kWsHeadStride, (unsigned)kMissedChunk);
+            j0 = (unsigned)__builtin_amdgcn_readfirstlane((int)j0);
+            if (j0 >= len) break;
+            const unsigned j1 = min(j0 + (unsigned)kMissedChunk, len);
+            for (unsigned j = j0; j < j1; ++j) {
+                const uint32_t rid = (uint32_t)__builtin_amdgcn_readfirstlane((int)lists[(size_t)l * (size_t)band + j]);
+                if (general) {
+                    if (!zeroed) {   // heads and validity bits of a ray without a valid sample: all zero, for every ray alike
+                        for (int i = lane; i < kSlotWords; i += 64) scratch[i] = 0u;
+                        zeroed = true;
+                    }
+                    if (lane == 0) {
+                        scratch[SL_RID] = rid;
+                        *reinterpret_cast<RayRec *>(scratch + SL_REC) = recs[rid];
+                    }
+                    ray_sample_stage<SPL>(ak, l_btab, scratch, mult_w, lane);
+                    ray_composite_stage<SPL>(ak, scratch, mult_w, lane);
+                } else {
+                    missed_ray_short_cut<SPL>(ak, rid, recs[rid], cdf, lane);
                 }
-                if (lane == 0) {
-                    scratch[SL_RID] = rid;
-                    *reinterpret_cast<RayRec *>(scratch + SL_REC) = recs[rid];
-                }
-                ray_sample_stage<SPL>(ak, l_btab, scratch, mult_w, lane);
-                ray_composite_stage<SPL>(ak, scratch, mult_w, lane);
-            } else {
-                missed_ray_short_cut<SPL>(ak, rid, recs[rid], cdf, lane);
+                done += 1;
             }
-            done += 1;
         }
     }
     return done;
