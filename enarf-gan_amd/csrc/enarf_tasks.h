@@ -448,7 +448,7 @@ __device__ __forceinline__ void missed_ray_short_cut(RenderArgsK a, uint32_t rid
 }
 
 #ifndef ENARF_MISSED_CHUNK
-#define ENARF_MISSED_CHUNK 8
+#define ENARF_MISSED_CHUNK 32
 #endif
 constexpr int kMissedChunk = ENARF_MISSED_CHUNK;
 template <int SPL>
