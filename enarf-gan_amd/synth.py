@@ -248,3 +248,12 @@ def nerf_config(**overrides) -> AttrDict:
                  no_selector=False, time_conditional=True, pose_conditional=False)
     c.update(overrides)
     return c
+
+
+def canonical_buffers(scene: Dict, origin_location: str = "center_fixed", style_dim: int = 20):
+    """(canonical_pose (P,4,4), canonical_bone_length (P,1)) of a synthetic scene from the product's own
+    TriPlaneNARF.register_canonical_pose (models/narf.py:84-120) - what the measurement tools hand to the C ABI."""
+    from .models.narf import TriPlaneNARF
+    m = TriPlaneNARF(nerf_config(origin_location=origin_location), style_dim, 24, parent=scene["parents"], num_bone_param=23)
+    m.register_canonical_pose(scene["canonical_pose"])
+    return m.canonical_pose, m.canonical_bone_length

@@ -1,7 +1,7 @@
 """CPU analysis (not product, not a test): valid-part counts per coarse sample of the bench scene, to size the
 lane utilisation / wave balance of the gather rounds under different sample->wave assignments."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from enarf_gan_amd import synth
 from oracle import enarf_oracle as O

@@ -22,12 +22,11 @@ def _maybe_variant():
 
 
 _maybe_variant()
-from oracle import enarf_oracle as O  # noqa: E402  (canonical buffers of the synthetic scene only)
 
 S, B, Nc, Nf = int(os.environ.get("SIZE", 128)), int(os.environ.get("BATCH", 1)), 48, 64
 dev = torch.device("cuda:0")
 sc = synth.make_scene(S, B, "center_fixed", 20, shared_triplane=True)
-cpose, cbl = O.register_canonical_pose(sc["canonical_pose"], sc["parents"], "center_fixed")
+cpose, cbl = synth.canonical_buffers(sc, "center_fixed")
 d = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in sc.items()}
 tri = sc["tri_plane"][:1].contiguous().to(dev)
 if os.environ.get("DISTINCT") and B > 1:      # GAN style: one tri-plane per frame
