@@ -2,7 +2,6 @@
 set -eo pipefail
 ulimit -c 0
 O=gpurun_out/r2y; mkdir -p $O
-python tools/bench_bwd.py 2>&1 | grep -v amdgpu.ids | tail -2 | tee $O/bwd.log
-BATCH=8 python tools/bench_bwd.py 2>&1 | grep -v amdgpu.ids | tail -1 | tee -a $O/bwd.log
-python tools/cand_hist.py 2>&1 | grep -v amdgpu.ids | tail -6 | tee $O/cand.log
-python tools/bench_mesh.py 2>&1 | grep -v amdgpu.ids | tail -2 | tee $O/mesh.log
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/bwd_stats -- python3 $GRAFT_REPO_ROOT/tools/bench_bwd.py > $GRAFT_REPO_ROOT/$O/bwd_stats.log 2>&1
+find $GRAFT_REPO_ROOT/$O/bwd_stats -name "*kernel_stats.csv" | while read f; do cut -d, -f1-4 $f | head -12; done
