@@ -90,9 +90,10 @@ __global__ __launch_bounds__(256) void pack_kernel(const float *__restrict__ in,
 // `separate`: the three planes' samples are written side by side, out (B, 3, C, n), instead of summed (the callers of
 // sample_feature's "prod" reduction need them apart, sampling.py:43-48). `point_image`: per-point image index (then the grid
 // has batch 1): the semantics of sample_feature's batch_idx without its side-by-side copy of the planes (sampling.py:34-38).
+template <bool separate>
 __global__ __launch_bounds__(256) void sample_fwd_direct(const float *__restrict__ in, const float *__restrict__ grid,
                                                          float *__restrict__ out, int C, int H, int W, long long n,
-                                                         SamplerCfg cfg, int separate, const int *__restrict__ point_image) {
+                                                         SamplerCfg cfg, const int *__restrict__ point_image) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     const int b = blockIdx.y;
     if (i >= n) return;
@@ -448,8 +449,8 @@ extern "C" int enarf_triplane_sample_fwd(const float *input, const float *grid, 
         }
         return host::check_launch("enarf_triplane_sample_fwd");
     }
-    hipLaunchKernelGGL(sample_fwd_direct, dim3((unsigned)((n_pts + 255) / 256), B), dim3(256), 0, st, input, grid, out,
-                       C, H, W, n_pts, cfg, 0, (const int *)nullptr);
+    hipLaunchKernelGGL(sample_fwd_direct<false>, dim3((unsigned)((n_pts + 255) / 256), B), dim3(256), 0, st, input, grid, out,
+                       C, H, W, n_pts, cfg, (const int *)nullptr);
     return host::check_launch("enarf_triplane_sample_fwd");
 }
 
@@ -468,8 +469,11 @@ extern "C" int enarf_triplane_sample_ex_fwd(const float *input, const float *gri
     if (int rc = check_ex("enarf_triplane_sample_ex_fwd", B, n_images, point_image, reduction)) return rc;
     if (n_pts == 0) return 0;
     const SamplerCfg cfg{interp, pad, align_corners ? 1 : 0};
-    hipLaunchKernelGGL(sample_fwd_direct, dim3((unsigned)((n_pts + 255) / 256), B), dim3(256), 0, (hipStream_t)stream, input, grid,
-                       out, C, H, W, n_pts, cfg, reduction == ENARF_PLANES_SEPARATE ? 1 : 0, point_image);
+    const dim3 grd((unsigned)((n_pts + 255) / 256), B);
+    if (reduction == ENARF_PLANES_SEPARATE)
+        hipLaunchKernelGGL(sample_fwd_direct<true>, grd, dim3(256), 0, (hipStream_t)stream, input, grid, out, C, H, W, n_pts, cfg, point_image);
+    else
+        hipLaunchKernelGGL(sample_fwd_direct<false>, grd, dim3(256), 0, (hipStream_t)stream, input, grid, out, C, H, W, n_pts, cfg, point_image);
     return host::check_launch("enarf_triplane_sample_ex_fwd");
 }
 

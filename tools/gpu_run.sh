@@ -1,6 +1,6 @@
 #!/bin/bash
 # tests + smoke + bench + kernel-trace profile on the GPU box
-set -o pipefail
+set -eo pipefail
 mkdir -p gpurun_out
 python -m pytest tests -m gpu -q 2>&1 | tee gpurun_out/pytest_gpu.log | tail -15
 python __graft_entry__.py --smoke 2>&1 | tail -2
