@@ -185,6 +185,29 @@ __global__ void mlp_unpack_kernel(const float *__restrict__ pf, float *__restric
     }
 }
 
+// Squared radius (x 1.01) of the sphere around a part's origin that contains its local cube |R^T (p - t)|_inf <= 1: the
+// farthest corner of the parallelepiped R^-T [-1, 1]^3 - 3 for a rotation, but computed from the matrix so that a
+// non-rigid frame is never culled wrongly (a singular one gives an unbounded radius). F: R row-major (part frame record).
+__device__ __forceinline__ float part_cull_radius2(const float *F) {
+    // M = R^T (local = M d), rows (a b c; d e f; g h i)
+    const float a = F[0], b = F[3], c = F[6], d = F[1], e = F[4], f = F[7], g = F[2], h = F[5], i = F[8];
+    const float A = e * i - f * h, B = f * g - d * i, C = d * h - e * g;
+    const float det = a * A + b * B + c * C;
+    if (!(fabsf(det) > 1e-20f)) return 3.0e38f;
+    const float r = 1.0f / det;
+    const float n00 = A * r, n01 = (c * h - b * i) * r, n02 = (b * f - c * e) * r;
+    const float n10 = B * r, n11 = (a * i - c * g) * r, n12 = (c * d - a * f) * r;
+    const float n20 = C * r, n21 = (b * g - a * h) * r, n22 = (a * e - b * d) * r;
+    float r2 = 0.0f;
+#pragma unroll
+    for (int sgn = 0; sgn < 4; ++sgn) {      // corners (1, +-1, +-1); the other four are their negatives
+        const float sy = (sgn & 1) ? -1.0f : 1.0f, sz = (sgn & 2) ? -1.0f : 1.0f;
+        const float x = n00 + n01 * sy + n02 * sz, y = n10 + n11 * sy + n12 * sz, z = n20 + n21 * sy + n22 * sz;
+        r2 = fmaxf(r2, x * x + y * y + z * z);
+    }
+    return r2 * 1.01f;
+}
+
 // =================================================================================================
 // enarf_query_fwd: a wave takes 16 points at a time (one MFMA tile), 4 adjacent lanes per point
 // =================================================================================================
@@ -205,8 +228,12 @@ __global__ __launch_bounds__(256) void query_kernel(const enarf_query_args a, in
 #if ENARF_DIAG_TAPCHECK
     S.diag = nullptr; S.diag_rid = 0;
 #endif
-    int *l_cand = reinterpret_cast<int *>(scratch + 8);
-    if (tid < a.P) l_cand[tid] = tid;                 // every part is a candidate for a free point cloud
+    // candidates of a 16-point tile: the parts whose bounding sphere contains at least one of its points (a free point
+    // cloud - or the lattice of create_mesh, mostly empty space - has no ray set-up to cull for it); debug runs keep
+    // every part, they export the canonical coordinates of all of them
+    int *l_cand = reinterpret_cast<int *>(scratch + 128) + wave * 32;
+    float *l_rad2 = scratch + 64;
+    if (tid < a.P) l_rad2[tid] = part_cull_radius2(S.parts + tid * kLdsPartStride);
     __syncthreads();
 
     // colour of a point with no valid part: the reference still runs the MLP on a zero feature
@@ -249,7 +276,20 @@ __global__ __launch_bounds__(256) void query_kernel(const enarf_query_args a, in
         uint32_t bits;
         float wmax;
         unsigned np = 0, nt = 0;
-        query_tile<MODE, DBG>(S, l_cand, a.P, px, py, pz, active, lane, o, ran, bits, wmax, dbg, np, nt);
+        uint32_t near_parts = 0;
+        if (DBG) {
+            near_parts = (a.P >= 32) ? 0xFFFFFFFFu : ((1u << a.P) - 1u);
+        } else {
+            for (int k = lane & 3; k < a.P; k += 4) {
+                const float *F = S.parts + k * kLdsPartStride;
+                const float ex = px - F[9], ey = py - F[10], ez = pz - F[11];
+                if (active && ex * ex + ey * ey + ez * ez <= l_rad2[k]) near_parts |= 1u << k;
+            }
+#pragma unroll
+            for (int m = 1; m < 64; m <<= 1) near_parts |= (uint32_t)__shfl_xor((int)near_parts, m);
+        }
+        const int ncand = build_cand_list(l_cand, near_parts, lane);
+        query_tile<MODE, DBG>(S, l_cand, ncand, px, py, pz, active, lane, o, ran, bits, wmax, dbg, np, nt);
         // MFMA-layout lanes 0..15 hold the head of point (lane); fetch that point's bits / wmax from its quad
         const uint32_t pbits = (uint32_t)__shfl((int)bits, (lane & 15) << 2);
         const float pwmax = __shfl(wmax, (lane & 15) << 2);

@@ -1,12 +1,13 @@
 """Diagnosis: the two march kernels (and repeated runs of each) on one case; prints where outputs differ."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 from _helpers import DeviceScene, Scene
 if os.environ.get("ENARF_VARIANT"):
     from enarf_gan_amd import _lib
-    _lib.use_variant(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "variants", f"libenarf_{os.environ['ENARF_VARIANT']}.so"))
+    _lib.use_variant(os.path.join(ROOT, "variants", f"libenarf_{os.environ['ENARF_VARIANT']}.so"))
     print("variant", _lib.library_info()["path"])
 
 S, B, Nc, Nf, n0, nr = [int(x) for x in sys.argv[1:7]] if len(sys.argv) >= 7 else (64, 1, 48, 64, 0, 4096)

@@ -3,8 +3,8 @@
 set -eo pipefail
 ulimit -c 0
 O=gpurun_out/r2r; mkdir -p $O
-python tools/diag_march_eq.py 2>&1 | grep -v amdgpu.ids | grep "counters\|differs" | tee $O/diag.log
-DEBUG=0 python tools/diag_march_eq.py 32 3 24 32 5 333 2>&1 | grep -v amdgpu.ids | grep "counters\|differs" | tee $O/diag_b3.log
+python tests/analysis/diag_march_eq.py 2>&1 | grep -v amdgpu.ids | grep "counters\|differs" | tee $O/diag.log
+DEBUG=0 python tests/analysis/diag_march_eq.py 32 3 24 32 5 333 2>&1 | grep -v amdgpu.ids | grep "counters\|differs" | tee $O/diag_b3.log
 rc=0; python -m pytest tests -m gpu -q > $O/pytest_full.log 2>&1 || rc=$?
 grep -v amdgpu.ids $O/pytest_full.log | tail -12 | tee $O/pytest.log
 if [ $rc -gt 1 ]; then echo "pytest rc=$rc: stopping"; exit $rc; fi

@@ -2,7 +2,9 @@
 set -eo pipefail
 ulimit -c 0
 O=gpurun_out/r2y; mkdir -p $O
-rc=0; python -m pytest tests/test_gpu_parity.py tests/test_gpu_api.py -m gpu -q -k "sampler or sampling" > $O/pytest_full.log 2>&1 || rc=$?
-grep -v amdgpu.ids $O/pytest_full.log | tail -4
-if [ $rc -gt 1 ]; then exit $rc; fi
-python tools/bench_sampler.py 2>&1 | grep -v amdgpu.ids | tail -4
+python tools/bench_mesh.py 2>&1 | grep -v amdgpu.ids | tail -2
+OFFSET=100 python tools/bench_mesh.py 2>&1 | grep -v amdgpu.ids | tail -2
+OFFSET=1.5 python tools/bench_mesh.py 2>&1 | grep -v amdgpu.ids | tail -1
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/mesh_stats -- python3 $GRAFT_REPO_ROOT/tools/bench_mesh.py > $GRAFT_REPO_ROOT/$O/mesh_stats.log 2>&1
+find $GRAFT_REPO_ROOT/$O/mesh_stats -name "*kernel_stats.csv" | while read f; do cut -d, -f1-7 $f | head -5; done
