@@ -420,6 +420,9 @@ def main():
         prof = counter_fractions(workload_key, kern_ms) if not args.variant else None
         if prof is not None:          # measured HBM traffic and unit utilisations of THIS workload (rocprofv3, profiles/)
             roof["traffic"] = prof.get("hbm_bytes_per_launch")
+            if roof["traffic"]:      # the HBM roofline of the same launch, from the counters: far from the bound
+                roof["hbm"] = {"achieved": roof["traffic"] / t_k / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": roof["traffic"] / t_k / 1e9 / HBM_PEAK_GBS}
             roof["counters"] = prof.get("fractions")
             roof["profiled_kernel_ms"] = prof.get("kernel_ms")
         mode_label = {"f32": "f32", "f16x3": "f32 (MLP products as 3-term split fp16 on MFMA, fp32 accumulate)",
