@@ -230,9 +230,12 @@ typedef struct {
     float *dbg_fine_color;                /* (B, 3, n, Nf) */
     uint32_t *dbg_fine_valid;             /* (B, n, Nf) bit masks */
     float *dbg_bins;                      /* (B, n, Nf) the bins actually used */
-    unsigned long long *counters;         /* [0] valid (part,point) pairs sampled, [1] MLP tiles of 16 points run,
-                                             [2] rays marched, [3] gather rounds (wave-level), [4] fine tiles skipped by early_stop_eps; (5 x u64) atomically
-                                             accumulated; NULL = not counted */
+    unsigned long long *counters;         /* 8 x u64, atomically accumulated (zero them before the call); NULL = not counted.
+                                             [0] valid (part,point) pairs sampled, [1] MLP tiles of 16 points run,
+                                             [2] rays marched (rays that miss every cube included, dropped rays not),
+                                             [3] gather rounds (wave-level), [4] fine tiles skipped by early_stop_eps,
+                                             [5], [6] unused by the product library, [7] != 0: the task march's
+                                             scheduler watchdog fired and the outputs are incomplete (never expected) */
     void *workspace;                      /* device, >= enarf_render_workspace_bytes(B, n): two queue headers, per-ray
                                              records (depth range, candidate parts, direction) and the ray lists; one
                                              workspace must not be shared by launches that can overlap. */
