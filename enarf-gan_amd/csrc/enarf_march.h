@@ -69,7 +69,7 @@ static_assert(sizeof(RayRec) == 32, "RayRec");
 // workspace: [header kWsHeaderBytes][RayRec x B*n][ray lists: kNumLists x band_size entries]
 // lists: (band q, cost class c) -> id q * kClasses + c, then one list per band of the live rays WITHOUT any candidate part
 // (id ws_missed_list(q); batches only - a single image drops such rays, rendering.py:107-110): they need no query at all.
-// header (u32): [1] live rays, [kWsCountsOff + id] entries in list id, [kWsHeadsOff + 16 * id] queue head of list id -
+// header (u32): [1] rays filed for the march, [2] rays filed as missing every cube, [kWsCountsOff + id] entries in list id, [kWsHeadsOff + 16 * id] queue head of list id -
 // one 64-B slot per head, so that the atomics of different lists do not share a cache line
 constexpr int kQueues = 8;
 #ifndef ENARF_NUM_CLASSES

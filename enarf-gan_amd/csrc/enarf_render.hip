@@ -540,7 +540,7 @@ __device__ __forceinline__ void ray_setup_block(const enarf_render_args &a, cons
         const int tot = l_cnt[tid] + l_cnt[kFile + tid] + l_cnt[2 * kFile + tid] + l_cnt[3 * kFile + tid];
         const int lid = (tid < kClasses) ? q * kClasses + tid : ws_missed_list(q);
         l_cnt[4 * kFile + tid] = tot ? (int)atomicAdd(wsh + kWsCountsOff + lid, (unsigned int)tot) : 0;
-        if (tot) atomicAdd(wsh + 1, (unsigned int)tot);
+        if (tot) atomicAdd(wsh + ((tid < kClasses) ? 1 : 2), (unsigned int)tot);     // [1] rays to march, [2] rays that miss every cube
     }
     __syncthreads();
     if (file_it) {

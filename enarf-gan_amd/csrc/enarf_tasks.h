@@ -458,6 +458,7 @@ __device__ __forceinline__ unsigned march_missed_rays(RenderArgsK ak, const floa
     unsigned int *wsh = reinterpret_cast<unsigned int *>(const_cast<char *>(ws) + ws_header_off(ak->ws_epoch));
     const uint32_t *lists = reinterpret_cast<const uint32_t *>(ws + ws_list_off((long long)B * n));
     const RayRec *recs = reinterpret_cast<const RayRec *>(ws + ws_records_off());
+    if (wsh[2] == 0u) return 0u;                 // no such ray in this launch (always so for a single image): one load
     const long long band = ws_band_size(B, n);
     const int home = xcc_id() & (kQueues - 1);
     // debug runs (taps wanted) and the diagnostic fixed-grid build take the two general stages on a zeroed scratch slot
