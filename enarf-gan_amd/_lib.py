@@ -27,7 +27,8 @@ def library_info() -> dict:
     """What is (or will be) loaded: path and whether it is a variant build - bench.py prints this."""
     return {"path": LIB_PATH, "variant": _variant}
 
-ABI_VERSION = 2
+ABI_VERSION = 3
+STATUS_MARCH_WATCHDOG = 1                      # ENARF_STATUS_* (include/enarf_hip.h)
 MAX_JOINTS = 32
 MAX_PARTS = 32
 FEAT_DIM = 32
@@ -94,8 +95,8 @@ class RenderBwdArgs(C.Structure):
         ("g_color", _f32p), ("g_mask", _f32p), ("g_disparity", _f32p),
         ("grad_feat_cl", _f32p), ("grad_feat_batch_stride", C.c_longlong),
         ("grad_mask_planes", _f32p), ("grad_mask_batch_stride", C.c_longlong),
-        ("rows_x", _f32p), ("rows_h1", _f32p), ("rows_h2", _f32p), ("rows_dz1", _f32p), ("rows_dz2", _f32p),
-        ("rows_dz3", _f32p), ("rows_per_image", C.c_longlong), ("row_blocks", _f32p), ("workspace", _f32p),
+        ("rows_x", _f32p), ("rows_dz3", _f32p), ("rows_per_image", C.c_longlong), ("row_blocks", _f32p),
+        ("workspace", _f32p), ("counters", _f32p),
         ("clamp_mask", C.c_int), ("uniform_part_weight", C.c_int), ("multiply_density_with_weight", C.c_int),
     ]
 
@@ -109,8 +110,7 @@ class QueryBwdArgs(C.Structure):
         ("mlp_pack", _f32p), ("g_density", _f32p), ("g_color", _f32p),
         ("grad_feat_cl", _f32p), ("grad_feat_batch_stride", C.c_longlong),
         ("grad_mask_planes", _f32p), ("grad_mask_batch_stride", C.c_longlong),
-        ("rows_x", _f32p), ("rows_h1", _f32p), ("rows_h2", _f32p), ("rows_dz1", _f32p), ("rows_dz2", _f32p),
-        ("rows_dz3", _f32p), ("rows_per_image", C.c_longlong), ("row_blocks", _f32p),
+        ("rows_x", _f32p), ("rows_dz3", _f32p), ("rows_per_image", C.c_longlong), ("row_blocks", _f32p),
         ("clamp_mask", C.c_int), ("uniform_part_weight", C.c_int), ("multiply_density_with_weight", C.c_int),
     ]
 
@@ -118,8 +118,8 @@ class QueryBwdArgs(C.Structure):
 class WeightGradArgs(C.Structure):
     _fields_ = [
         ("B", C.c_int),
-        ("rows_x", _f32p), ("rows_h1", _f32p), ("rows_h2", _f32p), ("rows_dz1", _f32p), ("rows_dz2", _f32p),
-        ("rows_dz3", _f32p), ("rows_per_image", C.c_longlong), ("row_blocks", _f32p),
+        ("rows_x", _f32p), ("rows_dz3", _f32p), ("mlp_pack", _f32p), ("rows_per_image", C.c_longlong),
+        ("row_blocks", _f32p),
         ("dW1", _f32p), ("dW2", _f32p), ("dW3", _f32p), ("db1", _f32p), ("db2", _f32p), ("db3", _f32p),
         ("workspace", _f32p),
     ]
@@ -140,6 +140,7 @@ SIGNATURES = {
     "enarf_query_bwd_rows_per_image": (C.c_longlong, [C.c_longlong]),
     "enarf_query_bwd": (C.c_int, [C.POINTER(QueryBwdArgs), C.c_void_p]),
     "enarf_last_error": (C.c_char_p, []),
+    "enarf_device_status": (C.c_int, [C.POINTER(C.c_uint), C.c_int]),
     "enarf_triplane_sample_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
     "enarf_triplane_sample_bwd_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
     "enarf_triplane_sample_fwd": (C.c_int, [_f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_longlong,
@@ -203,9 +204,32 @@ def load() -> C.CDLL:
     return lib
 
 
+def device_status(clear: bool = True) -> int:
+    """ENARF_STATUS_* flags kernels of the CURRENT device have raised since the last clear (enarf_device_status): a word
+    of pinned host memory, read without a synchronisation - it covers every launch that has completed."""
+    flags = C.c_uint(0)
+    lib = load()
+    rc = lib.enarf_device_status(C.byref(flags), int(clear))
+    if rc != 0:
+        raise EnarfHipError(f"enarf_device_status failed (code {rc}): {lib.enarf_last_error().decode(errors='replace')}")
+    return int(flags.value)
+
+
+def raise_on_device_status(what: str) -> None:
+    flags = device_status(clear=True)
+    if flags & STATUS_MARCH_WATCHDOG:
+        raise EnarfHipError(f"{what}: an earlier enarf_render_fwd launch on this device was abandoned by its scheduler "
+                            "watchdog (ENARF_STATUS_MARCH_WATCHDOG): the outputs of that launch are incomplete")
+    if flags:
+        raise EnarfHipError(f"{what}: device status {flags:#x}")
+
+
 def check(rc: int, what: str) -> None:
+    """Every call through the C ABI ends here: its own return code first, then the device's sticky status word - a kernel
+    that gave up (the task march's watchdog) is reported by the next call on that device, whatever the caller asked for."""
     if rc != 0:
         msg = load().enarf_last_error().decode(errors="replace")
         if rc == -2:
             raise NotImplementedError(f"{what}: {msg}")
         raise EnarfHipError(f"{what} failed (code {rc}): {msg}")
+    raise_on_device_status(what)

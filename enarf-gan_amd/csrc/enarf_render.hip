@@ -233,7 +233,9 @@ __global__ __launch_bounds__(256) void query_kernel(const enarf_query_args a, in
     // every part, they export the canonical coordinates of all of them
     int *l_cand = reinterpret_cast<int *>(scratch + 128) + wave * 32;
     float *l_rad2 = scratch + 64;
-    if (tid < a.P) l_rad2[tid] = part_cull_radius2(S.parts + tid * kLdsPartStride);
+    // stage_common ends without a barrier and part k's record is written by threads 16k..16k+15 (waves 1-3 for k >= 4):
+    // the radius is taken from the GLOBAL record, so no wave reads LDS another wave may not have written yet
+    if (tid < a.P) l_rad2[tid] = part_cull_radius2(a.parts + ((size_t)b * a.P + tid) * kPartStride);
     __syncthreads();
 
     // colour of a point with no valid part: the reference still runs the MLP on a zero feature
@@ -990,6 +992,15 @@ using namespace enarf;
 
 extern "C" int enarf_abi_version(void) { return ENARF_ABI_VERSION; }
 extern "C" int enarf_version(void) { return ENARF_ABI_VERSION; }
+
+extern "C" int enarf_device_status(unsigned int *flags, int clear) {
+    if (!flags) return host::fail(ENARF_ERR_ARG, "enarf_device_status: flags is null");
+    volatile unsigned int *w = host::status_word(false);
+    if (!w) return host::fail((int)hipErrorOutOfMemory, "enarf_device_status: no status word for this device (pinned host allocation failed)");
+    *flags = w[0];
+    if (clear && *flags) __atomic_fetch_and(const_cast<unsigned int *>(w), ~*flags, __ATOMIC_RELAXED);
+    return 0;
+}
 extern "C" const char *enarf_last_error(void) { return host::last_error(); }
 extern "C" size_t enarf_mlp_pack_bytes(void) { return kPackBytes; }
 
@@ -1046,6 +1057,8 @@ static int check_common(const char *who, int B, int P, int H, int W, int mode, c
                         const void *feat, const void *mask, const void *pack) {
     if (B <= 0 || P <= 0 || P > ENARF_MAX_PARTS) return host::fail(ENARF_ERR_ARG, "%s: bad B=%d or P=%d (max %d parts)", who, B, P, ENARF_MAX_PARTS);
     if (H <= 0 || W <= 0) return host::fail(ENARF_ERR_ARG, "%s: bad plane size %dx%d", who, H, W);
+    // the part-probability taps of a row are fetched as ONE pair of adjacent floats (load_row_pair): a row has two columns
+    if (W < 2 || H < 2) return host::fail(ENARF_ERR_UNSUPPORTED, "%s: planes of %dx%d: at least 2x2 texels", who, H, W);
     // 32-bit byte offsets inside one image's planes (and 24-bit row * width products): 3 P part-probability planes of 4 B,
     // 3 feature planes of 128 B per texel
     if ((unsigned long long)3 * P * H * W * 4 >= (1ull << 32) || (unsigned long long)3 * H * W * 128 >= (1ull << 31) || H >= (1 << 23) || W >= (1 << 23))
@@ -1141,7 +1154,7 @@ static int launch_task_march(const enarf_render_args &a, hipStream_t st, bool wi
     }
     if (with_setup)
         if (int rc = launch_ray_setup(a, st)) return rc;
-    hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(NW * 64), lds, st, a, nslots);
+    hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(NW * 64), lds, st, a, nslots, host::status_word(true));
     return host::check_launch("enarf_render_fwd");
 }
 

@@ -14,6 +14,9 @@
 #include "enarf_march.h"
 #include "enarf_host.h"
 
+#ifndef ENARF_BWD_NS_FIXED
+#define ENARF_BWD_NS_FIXED 0
+#endif
 #ifndef ENARF_BWD_ABLATE
 #define ENARF_BWD_ABLATE 0      // diagnosis builds only: 1 no feature atomics, 2 no mask atomics, 4 no scatter pass, 8 no row export
 #endif
@@ -22,23 +25,25 @@ namespace enarf {
 
 constexpr int kBwdWavesPerSimd = 2;
 
-// LDS scratch of the backward kernel (floats)
+// LDS scratch of the backward kernel (floats). NS = stride of the per-sample arrays: 64 for Nf <= 64 and for the point
+// kernel, 128 for 64 < Nf <= 128. Sized by NS, not by the maximum: with P = 23 the fixed 128-sample layout came to 82.1 KB
+// per workgroup - 256 B too many for two workgroups on a CU's 160 KB, i.e. ONE wave per SIMD for the whole backward.
 constexpr int kBwdMaxSamples = 128;
 constexpr int SB_CAND = 0;                                  // 4 waves x 32 ints
-constexpr int SB_FH = 128;                                  // head [4][128]
-constexpr int SB_FBITS = SB_FH + 4 * kBwdMaxSamples;        // bits [128]
-constexpr int SB_DZ3 = SB_FBITS + kBwdMaxSamples;           // dL/dz3 [4][128]
-constexpr int SB_WMAX = SB_DZ3 + 4 * kBwdMaxSamples;        // multiply_density_with_triplane_wieght: max part weight [128]
-constexpr int SB_KMAX = SB_WMAX + kBwdMaxSamples;           //   the part that attains it [128] (ints)
-constexpr int SB_GWM = SB_KMAX + kBwdMaxSamples;            //   dL/d(max weight) [128]
-constexpr int SB_QUEUE = SB_GWM + kBwdMaxSamples;           // 2 ray slots
-constexpr int kBwdScratchFloats = SB_QUEUE + 64;
-static_assert(SB_QUEUE + kQueueLdsInts <= kBwdScratchFloats, "scratch overflow");
+constexpr int SB_FH = 128;                                  // head [4][NS]
+__host__ __device__ constexpr int sb_fbits(int NS) { return SB_FH + 4 * NS; }          // bits [NS]
+__host__ __device__ constexpr int sb_dz3(int NS) { return sb_fbits(NS) + NS; }         // dL/dz3 [4][NS]
+__host__ __device__ constexpr int sb_wmax(int NS) { return sb_dz3(NS) + 4 * NS; }      // multiply_density_with_triplane_wieght: max part weight [NS]
+__host__ __device__ constexpr int sb_kmax(int NS) { return sb_wmax(NS) + NS; }         //   the part that attains it [NS] (ints)
+__host__ __device__ constexpr int sb_gwm(int NS) { return sb_kmax(NS) + NS; }          //   dL/d(max weight) [NS]
+__host__ __device__ constexpr int sb_queue(int NS) { return sb_gwm(NS) + NS; }         // 2 ray slots
+__host__ __device__ constexpr int bwd_scratch_floats(int NS) { return sb_queue(NS) + 64; }
+static_assert(kQueueLdsInts <= 64, "scratch overflow");
 
 constexpr int kTRow = 33;                       // floats per texel row of the transpose tile (32 + 1 pad)
 constexpr int kTTile = 2 * 16 * kTRow + 32;      // two taps x (16 texel rows) + 2 x 16 texel offsets (ints)
-__host__ __device__ inline int bwd_lds_floats(int P) {
-    return PK_B1 + 144 + PKT_FLOATS + P * kLdsPartStride + P * kLdsCanonStride + kBwdScratchFloats + 4 * kTTile;
+__host__ __device__ inline int bwd_lds_floats(int P, int NS) {
+    return PK_B1 + 144 + PKT_FLOATS + P * kLdsPartStride + P * kLdsCanonStride + bwd_scratch_floats(NS) + 4 * kTTile;
 }
 
 // d loss / d one tap (texel) of every quad of the wave: grad[texel][c] += bilinear weight * w_k * dx[c].
@@ -51,7 +56,7 @@ __host__ __device__ inline int bwd_lds_floats(int P) {
 // along the ray, which mostly fall on the same texels: the importance samples cluster at the surface) that target the
 // same texel into ONE atomic.
 __device__ __forceinline__ void scatter_tap2(float *__restrict__ gpl, float *tile, int offA, float cfA, int offB, float cfB,
-                                             bool on, const float dxg[8], int lane) {
+                                             bool on, const float dxg[8], int lane, unsigned &n_lines) {
     const int q = lane >> 2, g = lane & 3;
     int *toff = reinterpret_cast<int *>(tile + 2 * 16 * kTRow);
     const bool liveA = on && cfA != 0.0f, liveB = on && cfB != 0.0f;
@@ -77,21 +82,21 @@ __device__ __forceinline__ void scatter_tap2(float *__restrict__ gpl, float *til
             if (o == run_o) {
                 run_v += v;
             } else {
-                if (run_o >= 0 && !(ENARF_BWD_ABLATE & 1)) atomicAdd(gpl + (size_t)run_o * kFeat + ch, run_v);
+                if (run_o >= 0 && !(ENARF_BWD_ABLATE & 1)) { atomicAdd(gpl + (size_t)run_o * kFeat + ch, run_v); n_lines += 1; }
                 run_o = o;
                 run_v = v;
             }
         }
-        if (run_o >= 0 && !(ENARF_BWD_ABLATE & 1)) atomicAdd(gpl + (size_t)run_o * kFeat + ch, run_v);
+        if (run_o >= 0 && !(ENARF_BWD_ABLATE & 1)) { atomicAdd(gpl + (size_t)run_o * kFeat + ch, run_v); n_lines += 1; }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 __device__ __forceinline__ void scatter_plane(float *__restrict__ gpl, float *tile, const Taps &t, float wk, bool on,
-                                              const float dxg[8], int lane) {
-    scatter_tap2(gpl, tile, t.o00, t.w00 * wk, t.o01, t.w01 * wk, on, dxg, lane);
-    scatter_tap2(gpl, tile, t.o10, t.w10 * wk, t.o11, t.w11 * wk, on, dxg, lane);
+                                              const float dxg[8], int lane, unsigned &n_lines) {
+    scatter_tap2(gpl, tile, t.o00, t.w00 * wk, t.o01, t.w01 * wk, on, dxg, lane, n_lines);
+    scatter_tap2(gpl, tile, t.o10, t.w10 * wk, t.o11, t.w11 * wk, on, dxg, lane, n_lines);
 }
 
 
@@ -104,7 +109,7 @@ __device__ __forceinline__ int dpp_i(int old, int v, int ctrl_sel) {
          : ctrl_sel == 1 ? __builtin_amdgcn_update_dpp(old, v, 0x118, 0xF, 0xF, false)      // row_shr:8
                          : __builtin_amdgcn_update_dpp(old, v, 0x104, 0xF, 0xF, false);     // row_shl:4
 }
-__device__ __forceinline__ void mask_tap_add(float *__restrict__ gmask, bool on, int elem, float v, int lane) {
+__device__ __forceinline__ void mask_tap_add(float *__restrict__ gmask, bool on, int elem, float v, int lane, unsigned &n_adds) {
     const int key = on ? elem : -2 - lane;                        // inactive lanes never match a neighbour
     float acc = on ? v : 0.0f;
     int head = (dpp_i(-1, key, 0) != key) ? 1 : 0;                // run starts here (also at the start of a row)
@@ -119,7 +124,7 @@ __device__ __forceinline__ void mask_tap_add(float *__restrict__ gmask, bool on,
         if (!head) { acc += pv; head |= ph; }
     }
     const bool tail = dpp_i(-1, key, 2) != key;                   // the next quad starts another run (or the row ends)
-    if (on && tail) atomicAdd(gmask + elem, acc);
+    if (on && tail) { atomicAdd(gmask + elem, acc); n_adds += 1; }
 }
 
 // what the per-tile stages of the backward need besides the query context (shared by the ray and the point kernels)
@@ -127,11 +132,16 @@ struct BwdTile {
     int H, W;
     size_t mplane, fplane;
     const float *l_wt;                    // LDS: transposed weight section
-    float *rows_x, *rows_h1, *rows_h2, *rows_dz1, *rows_dz2, *rows_dz3;
+    float *rows_x, *rows_dz3;             // compact rows for enarf_weight_grad: the tile's features and dL/dz3
     long long rows_per_image;
     unsigned int *row_blocks;
     float *gfeat, *gmask;                 // this image's gradient planes
     float *ttile;                         // this wave's atomic-transpose tile (LDS)
+};
+// per-lane tallies of a wave for enarf_render_bwd_args.counters (summed over the wave when the kernel ends)
+struct BwdCount {
+    unsigned pairs, tiles, rounds;        // wave-uniform
+    unsigned lines, mask_adds;            // per lane: lines counts in lanes 0 and 32 only (one per 128-B half-wave atomic)
 };
 
 // F1, gather half: cube tests over the candidate parts, then the weighted features of the valid pairs (gather layout:
@@ -203,13 +213,13 @@ __device__ __forceinline__ void bwd_gather_tile(const QueryCtx &S, const BwdTile
 // gwm / kmax (gather layout, quad-uniform): multiply_density_with_triplane_wieght sends dL/d(max part weight) to that part
 __device__ __forceinline__ void bwd_backward_tile(const QueryCtx &S, const BwdTile &T, int b, float px, float py, float pz,
                                                   uint32_t bits, const f32x4 a1[4], const f32x4 a2[4], const float x[8],
-                                                  float dz3v, int lane, float gwm = 0.0f, int kmax = -1) {
+                                                  float dz3v, int lane, BwdCount &C, float gwm = 0.0f, int kmax = -1) {
     const int g4 = lane & 3, j4 = lane >> 2;
     const int mj = lane & 15, mg = lane >> 4;          // MFMA layout: point mj, k-group mg
     f32x4 dz2[4], dz1[4];
     float dxm[8];
     mlp_bwd_tile_f32(T.l_wt, a1, a2, dz3v, lane, dz2, dz1, dxm);
-    // rows for the weight gradients: block of 16 rows of image b
+    // compact rows for the weight gradients (enarf_weight_grad re-runs the MLP on them): block of 16 rows of image b
     unsigned int blk = 0;
     if (lane == 0) blk = atomicAdd(T.row_blocks + b, 1u);
     blk = (unsigned int)__builtin_amdgcn_readfirstlane((int)blk);
@@ -218,15 +228,9 @@ __device__ __forceinline__ void bwd_backward_tile(const QueryCtx &S, const BwdTi
         f32x4 *rx = reinterpret_cast<f32x4 *>(T.rows_x + row * 32 + 8 * mg);
         rx[0] = f32x4{x[0], x[1], x[2], x[3]};
         rx[1] = f32x4{x[4], x[5], x[6], x[7]};
-#pragma unroll
-        for (int ob = 0; ob < 4; ++ob) {
-            *reinterpret_cast<f32x4 *>(T.rows_h1 + row * 64 + 16 * ob + 4 * mg) = a1[ob];
-            *reinterpret_cast<f32x4 *>(T.rows_h2 + row * 64 + 16 * ob + 4 * mg) = a2[ob];
-            *reinterpret_cast<f32x4 *>(T.rows_dz1 + row * 64 + 16 * ob + 4 * mg) = dz1[ob];
-            *reinterpret_cast<f32x4 *>(T.rows_dz2 + row * 64 + 16 * ob + 4 * mg) = dz2[ob];
-        }
         T.rows_dz3[row * 4 + mg] = dz3v;
     }
+    C.tiles += 1;
     // d feature back in the gather layout
     float dxg[8];
     const int src2 = (g4 << 4) | j4;
@@ -239,6 +243,8 @@ __device__ __forceinline__ void bwd_backward_tile(const QueryCtx &S, const BwdTi
     while (true) {
         const uint64_t bal = __ballot(rem != 0);
         if (bal == 0) { __builtin_amdgcn_s_setprio(0); break; }
+        C.pairs += (unsigned)(__popcll(bal) >> 2);
+        C.rounds += 1;
         const bool act = rem != 0;
         const int k = act ? __builtin_ctz(rem) : 0;
         rem &= rem - 1;
@@ -279,15 +285,15 @@ __device__ __forceinline__ void bwd_backward_tile(const QueryCtx &S, const BwdTi
             const bool mon = act && g4 < 3 && !(ENARF_BWD_ABLATE & 2) && !(S.uniform_w > 0.0f);     // uniform weights: no plane gradient
             const float gm = mon ? dot * wp * (1.0f - sg) : 0.0f;
             const int pbase = (3 * k + g4) * (int)T.mplane;
-            mask_tap_add(T.gmask, mon && t.w00 != 0.0f, pbase + t.o00, t.w00 * gm, lane);
-            mask_tap_add(T.gmask, mon && t.w01 != 0.0f, pbase + t.o01, t.w01 * gm, lane);
-            mask_tap_add(T.gmask, mon && t.w10 != 0.0f, pbase + t.o10, t.w10 * gm, lane);
-            mask_tap_add(T.gmask, mon && t.w11 != 0.0f, pbase + t.o11, t.w11 * gm, lane);
+            mask_tap_add(T.gmask, mon && t.w00 != 0.0f, pbase + t.o00, t.w00 * gm, lane, C.mask_adds);
+            mask_tap_add(T.gmask, mon && t.w01 != 0.0f, pbase + t.o01, t.w01 * gm, lane, C.mask_adds);
+            mask_tap_add(T.gmask, mon && t.w10 != 0.0f, pbase + t.o10, t.w10 * gm, lane, C.mask_adds);
+            mask_tap_add(T.gmask, mon && t.w11 != 0.0f, pbase + t.o11, t.w11 * gm, lane, C.mask_adds);
         }
         // every lane takes part (wave-uniform): inactive quads contribute empty rows
-        scatter_plane(T.gfeat, T.ttile, t0, wk, act, dxg, lane);
-        scatter_plane(T.gfeat + T.fplane, T.ttile, t1, wk, act, dxg, lane);
-        scatter_plane(T.gfeat + 2 * T.fplane, T.ttile, t2, wk, act, dxg, lane);
+        scatter_plane(T.gfeat, T.ttile, t0, wk, act, dxg, lane, C.lines);
+        scatter_plane(T.gfeat + T.fplane, T.ttile, t1, wk, act, dxg, lane, C.lines);
+        scatter_plane(T.gfeat + 2 * T.fplane, T.ttile, t2, wk, act, dxg, lane, C.lines);
     }
 }
 
@@ -321,7 +327,12 @@ __global__ __launch_bounds__(256, kBwdWavesPerSimd) void render_bwd_kernel(const
     // LDS: [fp32 weights PK_B1][bias 144][transposed PKT_FLOATS][parts][canon][scratch]
     float *l_w = lds, *l_bias = l_w + PK_B1, *l_wt = l_bias + 144, *l_parts = l_wt + PKT_FLOATS;
     float *l_canon = l_parts + P * kLdsPartStride, *scratch = l_canon + P * kLdsCanonStride;
-    int *l_q = reinterpret_cast<int *>(scratch + SB_QUEUE);
+#if ENARF_BWD_NS_FIXED                               // A/B only: round 2's fixed 128-sample layout (one workgroup per CU)
+    constexpr int NS = kBwdMaxSamples;
+#else
+    constexpr int NS = 64 * SPL;                    // stride of the per-sample LDS arrays
+#endif
+    int *l_q = reinterpret_cast<int *>(scratch + sb_queue(NS));
     rq.init(a.workspace, 0, a.B, n, l_q, tid);      // the backward's own set-up launch runs with epoch 0
     if (tid == 0) rq.pop(0);
     __syncthreads();
@@ -333,21 +344,21 @@ __global__ __launch_bounds__(256, kBwdWavesPerSimd) void render_bwd_kernel(const
     S.H = a.H; S.W = a.W; S.P = P; S.mult_w = a.multiply_density_with_weight ? (a.uniform_part_weight ? 2 : 1) : 0;
     S.clamp_mask = a.clamp_mask; S.uniform_w = a.uniform_part_weight ? 1.0f / (float)P : 0.0f;
     int *l_cand = reinterpret_cast<int *>(scratch + SB_CAND) + wave * 32;
-    float *l_fh = scratch + SB_FH, *l_dz3 = scratch + SB_DZ3;
-    float *l_wmax = scratch + SB_WMAX, *l_gwm = scratch + SB_GWM;
-    int *l_kmax = reinterpret_cast<int *>(scratch + SB_KMAX);
-    float *ttile = scratch + kBwdScratchFloats + wave * kTTile;     // this wave's atomic-transpose tile
-    uint32_t *l_fbits = reinterpret_cast<uint32_t *>(scratch + SB_FBITS);
+    float *l_fh = scratch + SB_FH, *l_dz3 = scratch + sb_dz3(NS);
+    float *l_wmax = scratch + sb_wmax(NS), *l_gwm = scratch + sb_gwm(NS);
+    int *l_kmax = reinterpret_cast<int *>(scratch + sb_kmax(NS));
+    float *ttile = scratch + bwd_scratch_floats(NS) + wave * kTTile;     // this wave's atomic-transpose tile
+    uint32_t *l_fbits = reinterpret_cast<uint32_t *>(scratch + sb_fbits(NS));
     const int j4 = lane >> 2, g4 = lane & 3;
     const size_t mplane = (size_t)a.H * a.W, fplane = mplane * kFeat;
     int qslot = 0;
     BwdTile T;
     T.H = a.H; T.W = a.W; T.mplane = mplane; T.fplane = fplane; T.l_wt = l_wt;
-    T.rows_x = a.rows_x; T.rows_h1 = a.rows_h1; T.rows_h2 = a.rows_h2;
-    T.rows_dz1 = a.rows_dz1; T.rows_dz2 = a.rows_dz2; T.rows_dz3 = a.rows_dz3;
+    T.rows_x = a.rows_x; T.rows_dz3 = a.rows_dz3;
     T.rows_per_image = a.rows_per_image; T.row_blocks = a.row_blocks; T.ttile = ttile;
     T.gfeat = nullptr; T.gmask = nullptr;
-    constexpr int NS = kBwdMaxSamples;              // stride of the per-sample LDS arrays
+    BwdCount C = {0u, 0u, 0u, 0u, 0u};
+    unsigned c_rays = 0;
 
     while (cur >= 0) {
         if (tid == 0) rq.pop(qslot ^ 1);
@@ -500,11 +511,23 @@ __global__ __launch_bounds__(256, kBwdWavesPerSimd) void render_bwd_kernel(const
             const int ms = min(base + mj, Nf - 1);
             const float dz3v = (base + mj < Nf) ? l_dz3[mg * NS + ms] : 0.0f;
             const int si = min(base + j4, Nf - 1);             // gather layout: this quad's sample
-            bwd_backward_tile(S, T, b, px[u], py[u], pz[u], bits[u], a1, a2, x, dz3v, lane, l_gwm[si], l_kmax[si]);
+            bwd_backward_tile(S, T, b, px[u], py[u], pz[u], bits[u], a1, a2, x, dz3v, lane, C, l_gwm[si], l_kmax[si]);
         }
+        c_rays += 1;
         // the next ray's first barrier orders this ray's LDS reads (l_dz3, l_fh) before their next writes
         __syncthreads();
         cur = next_ray;
+    }
+    if (a.counters) {
+        const float nl = wave_sum((lane & 31) == 0 ? (float)C.lines : 0.0f), nm = wave_sum((float)C.mask_adds);   // < 2^24 per wave
+        if (lane == 0) {
+            atomicAdd(&a.counters[0], (unsigned long long)C.pairs);
+            atomicAdd(&a.counters[1], (unsigned long long)C.tiles);
+            if (wave == 0) atomicAdd(&a.counters[2], (unsigned long long)c_rays);
+            atomicAdd(&a.counters[3], (unsigned long long)nl);
+            atomicAdd(&a.counters[4], (unsigned long long)nm);
+            atomicAdd(&a.counters[5], (unsigned long long)C.rounds);
+        }
     }
 }
 
@@ -527,16 +550,17 @@ __global__ __launch_bounds__(256, kBwdWavesPerSimd) void query_bwd_kernel(const 
     S.feat = a.feat_cl + (size_t)b * a.feat_batch_stride;
     S.mask = a.mask_planes + (size_t)b * a.mask_batch_stride;
     int *l_cand = reinterpret_cast<int *>(scratch + SB_CAND);
-    float *l_fh = scratch + SB_FH, *l_dz3 = scratch + SB_DZ3;
-    float *l_wmax = scratch + SB_WMAX, *l_gwm = scratch + SB_GWM;
-    int *l_kmax = reinterpret_cast<int *>(scratch + SB_KMAX);
-    uint32_t *l_fbits = reinterpret_cast<uint32_t *>(scratch + SB_FBITS);
+    constexpr int NS = 64;
+    float *l_fh = scratch + SB_FH, *l_dz3 = scratch + sb_dz3(NS);
+    float *l_wmax = scratch + sb_wmax(NS), *l_gwm = scratch + sb_gwm(NS);
+    int *l_kmax = reinterpret_cast<int *>(scratch + sb_kmax(NS));
+    uint32_t *l_fbits = reinterpret_cast<uint32_t *>(scratch + sb_fbits(NS));
     BwdTile T;
     T.H = a.H; T.W = a.W; T.mplane = (size_t)a.H * a.W; T.fplane = T.mplane * kFeat; T.l_wt = l_wt;
-    T.rows_x = a.rows_x; T.rows_h1 = a.rows_h1; T.rows_h2 = a.rows_h2;
-    T.rows_dz1 = a.rows_dz1; T.rows_dz2 = a.rows_dz2; T.rows_dz3 = a.rows_dz3;
+    T.rows_x = a.rows_x; T.rows_dz3 = a.rows_dz3;
     T.rows_per_image = a.rows_per_image; T.row_blocks = a.row_blocks;
-    T.ttile = scratch + kBwdScratchFloats + wave * kTTile;
+    BwdCount C = {0u, 0u, 0u, 0u, 0u};
+    T.ttile = scratch + bwd_scratch_floats(NS) + wave * kTTile;
     T.gfeat = a.grad_feat_cl + (size_t)b * a.grad_feat_batch_stride;
     T.gmask = a.grad_mask_planes + (size_t)b * a.grad_mask_batch_stride;
     bwd_stage_image(a.mlp_pack, a.parts, a.canonical_pose, b, P, l_w, l_bias, l_wt, l_parts, l_canon, tid);
@@ -602,7 +626,7 @@ __global__ __launch_bounds__(256, kBwdWavesPerSimd) void query_bwd_kernel(const 
         if (ran) {
             const int mj = lane & 15, mg = lane >> 4;
             const float dz3v = l_dz3[mg * 64 + wave * 16 + mj];
-            bwd_backward_tile(S, T, b, px, py, pz, bits, a1, a2, x, dz3v, lane, l_gwm[wave * 16 + j4], l_kmax[wave * 16 + j4]);
+            bwd_backward_tile(S, T, b, px, py, pz, bits, a1, a2, x, dz3v, lane, C, l_gwm[wave * 16 + j4], l_kmax[wave * 16 + j4]);
         }
         __syncthreads();     // l_fh / l_dz3 are rewritten by the next tile
     }
@@ -625,67 +649,155 @@ __global__ __launch_bounds__(256) void unpack_add_kernel(const float *__restrict
         if (xb + x < W) dst[(size_t)c * H * W + xb + x] += tile[c * 65 + x];
 }
 
-// ---- weight gradients from the exported rows: dW_l = dZ_l^T H_{l-1}, db_l = sum_rows dZ_l ------------------------------
-// A reduction over ~0.5 M rows with 64 x 64 (64 x 32, 4 x 64) outputs: a library GEMM picks a tile shape made for big
-// outputs and spends 0.8 ms on each; here every WAVE streams its own chunk of rows through v_mfma_f32_16x16x4_f32
-// (4 rows per step, operands straight from coalesced 16-B loads: lane l reads row l/16, columns 4(l%16)..+3, and
-// register r of that load is the operand block "columns 4i + r" - a permutation of the output that the second kernel
-// undoes) and keeps all three products in 112 accumulator registers; the four waves of a workgroup add their partials
-// up in LDS and store one partial per 1024 rows; a second kernel sums the partials. No atomics: deterministic.
+// ---- weight gradients from the compact rows: dW_l = dZ_l^T H_{l-1}, db_l = sum_rows dZ_l ------------------------------
+// The backward kernels export, per valid 16-sample tile, only what cannot be recomputed from the MLP alone: the 32 gathered
+// features x and dL/dz3 (144 B per sample; all six activation rows were 1 168 B: 589 MB per C1 frame written and read back,
+// 1.2 GB of scratch). Here every wave takes its tiles through the exact-fp32 MLP forward (x -> h1, h2) and backward
+// (dz3 -> dz2, dz1) again - mlp_tile_f32_keep / mlp_bwd_tile_f32, the code the exporting kernel ran on the same operands -
+// and accumulates the three products over ALL its tiles in 112 accumulator registers.
+// The products contract over POINTS, which the MLP's layout keeps on the lane axis (lane = 16 g + point, registers =
+// units 16 ob + 4 g + r): each 16 x 16 block is transposed through a wave-private LDS tile (4 ds_write_b32, 1 ds_read_b128)
+// into "lane = 16 kk + unit, register s = point 4 kk + s", which is both the A operand (rows = units of dZ) and the B operand
+// (columns = units of H) of v_mfma_f32_16x16x4_f32 with k-step s contracting points {s, 4 + s, 8 + s, 12 + s}.
+// A fixed number of workgroups per image strides over the image's 1024-row chunks and stores ONE partial each; a second
+// kernel sums the partials in a fixed order. No atomics: deterministic for a given row order.
 constexpr int kWgRowsPerWave = 256, kWgRowsPerWg = 4 * kWgRowsPerWave;
 constexpr int kWgAcc2 = 0, kWgAcc1 = 16 * 256, kWgAcc3 = kWgAcc1 + 8 * 256, kWgSum2 = kWgAcc3 + 4 * 256;
-constexpr int kWgSum1 = kWgSum2 + 256, kWgSum3 = kWgSum1 + 256, kWgPartial = kWgSum3 + 64;      // floats per wave chunk
+constexpr int kWgSum1 = kWgSum2 + 64, kWgSum3 = kWgSum1 + 64, kWgPartial = kWgSum3 + 16;      // floats per partial
+constexpr int kWgTStride = 20;                            // floats per unit row of the transpose tile (16 points + pad; rows stay 16-B aligned)
+constexpr int kWgTTile = 4 * 16 * kWgTStride;             // one whole activation (64 units x 16 points) per wave
+constexpr int kWgLdsFloats = PK_B1 + 144 + PKT_FLOATS + 4 * kWgTTile;
+static_assert(kWgPartial <= PK_B1 + 144, "the partial is staged over the weights");
 
 struct WeightGradParams {
-    const float *x, *h1, *h2, *dz1, *dz2, *dz3;
+    const float *x, *dz3;
+    const void *pack;
     long long rows_per_image;
     const unsigned int *row_blocks;
-    float *partial;            // [B][chunks][kWgPartial]
-    int chunks;                // workgroup chunks (kWgRowsPerWg rows) per image the launch covers
+    float *partial;            // [B][groups][kWgPartial]
+    int groups;                // workgroups per image
     float *dW1, *dW2, *dW3, *db1, *db2, *db3;
 };
 
-__global__ __launch_bounds__(256) void weight_grad_partial_kernel(const WeightGradParams p) {
-    __shared__ float red[kWgPartial];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.y;
-    const int chunk = blockIdx.x;
+// E (4 blocks of f32x4: lane 16 g + j holds units 16 blk + 4 g + r of point j) -> Et[blk][s] = E[unit 16 blk + (lane & 15)][point 4 (lane >> 4) + s]
+__device__ __forceinline__ void wg_transpose(float *tt, const f32x4 e[4], f32x4 et[4], int lane) {
+    const int j = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tt[(blk * 16 + 4 * g + r) * kWgTStride + j] = e[blk][r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk) et[blk] = *reinterpret_cast<const f32x4 *>(tt + (blk * 16 + j) * kWgTStride + 4 * g);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// sum over the 16 lanes of a row (lanes 16 g .. 16 g + 15), result in the row's last lane
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_f<0x111, 0xF>(v);
+    v += dpp_f<0x112, 0xF>(v);
+    v += dpp_f<0x114, 0xF>(v);
+    v += dpp_f<0x118, 0xF>(v);
+    return v;
+}
+
+__global__ __launch_bounds__(256, 1) void weight_grad_partial_kernel(const WeightGradParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.y;
+    const int grp = blockIdx.x;
     const long long count = (long long)p.row_blocks[b] * 16;
-    if ((long long)chunk * kWgRowsPerWg >= count) return;      // block-uniform
-    const long long r0 = (long long)chunk * kWgRowsPerWg + (long long)wave * kWgRowsPerWave;
-    const long long r1 = (r0 + kWgRowsPerWave < count) ? r0 + kWgRowsPerWave : count;   // multiple of 16; may be <= r0
-    const int kg = lane >> 4, i16 = lane & 15;
-    const size_t base = (size_t)b * p.rows_per_image;
-    f32x4 acc2[16], acc1[8], acc3[4];
-#pragma unroll
-    for (int t = 0; t < 16; ++t) acc2[t] = f32x4{0, 0, 0, 0};
-#pragma unroll
-    for (int t = 0; t < 8; ++t) acc1[t] = f32x4{0, 0, 0, 0};
-#pragma unroll
-    for (int t = 0; t < 4; ++t) acc3[t] = f32x4{0, 0, 0, 0};
-    f32x4 s2 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0};
-    float s3 = 0.0f;
-    for (long long r = r0; r < r1; r += 4) {
-        const size_t row = base + (size_t)r + kg;
-        const f32x4 vdz2 = *reinterpret_cast<const f32x4 *>(p.dz2 + row * 64 + 4 * i16);
-        const f32x4 vh1 = *reinterpret_cast<const f32x4 *>(p.h1 + row * 64 + 4 * i16);
-        const f32x4 vdz1 = *reinterpret_cast<const f32x4 *>(p.dz1 + row * 64 + 4 * i16);
-        const f32x4 vh2 = *reinterpret_cast<const f32x4 *>(p.h2 + row * 64 + 4 * i16);
-        const float2 vx = *reinterpret_cast<const float2 *>(p.x + row * 32 + 2 * i16);
-        const float vdz3 = (i16 < 4) ? p.dz3[row * 4 + i16] : 0.0f;
-#pragma unroll
-        for (int ra = 0; ra < 4; ++ra) {
-#pragma unroll
-            for (int rb = 0; rb < 4; ++rb)
-                acc2[ra * 4 + rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(vdz2[ra], vh1[rb], acc2[ra * 4 + rb], 0, 0, 0);
-            acc1[ra * 2 + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(vdz1[ra], vx.x, acc1[ra * 2 + 0], 0, 0, 0);
-            acc1[ra * 2 + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(vdz1[ra], vx.y, acc1[ra * 2 + 1], 0, 0, 0);
-            acc3[ra] = __builtin_amdgcn_mfma_f32_16x16x4f32(vdz3, vh2[ra], acc3[ra], 0, 0, 0);
-        }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { s2[c] += vdz2[c]; s1[c] += vdz1[c]; }
-        s3 += vdz3;
+    if ((long long)grp * kWgRowsPerWg >= count) return;      // block-uniform: this workgroup has no chunk
+    float *l_w = lds, *l_bias = l_w + PK_B1, *l_wt = l_bias + 144, *tt = l_wt + PKT_FLOATS + wave * kWgTTile;
+    {
+        const float *pf = reinterpret_cast<const float *>(reinterpret_cast<const char *>(p.pack) + (size_t)b * kPackBytes);
+        const float *pt = reinterpret_cast<const float *>(reinterpret_cast<const char *>(pf) + kPackTOff);
+        for (int i = tid; i < PK_B1 / 4; i += 256) reinterpret_cast<f32x4 *>(l_w)[i] = reinterpret_cast<const f32x4 *>(pf)[i];
+        for (int i = tid; i < 144; i += 256) l_bias[i] = pf[PK_B1 + i];
+        for (int i = tid; i < PKT_FLOATS / 4; i += 256) reinterpret_cast<f32x4 *>(l_wt)[i] = reinterpret_cast<const f32x4 *>(pt)[i];
     }
-    // the four waves add up in LDS, one after the other (a wave with no rows adds zeros), then store once
+    __syncthreads();
+    const int j = lane & 15, g = lane >> 4;
+    const size_t base = (size_t)b * p.rows_per_image;
+    const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+    f32x4 acc2[16], acc1[8], acc3[4], s2[4], s1[4];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc2[t] = zero;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc1[t] = zero;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { acc3[t] = zero; s2[t] = zero; s1[t] = zero; }
+    float s3 = 0.0f;
+    for (long long c0 = (long long)grp * kWgRowsPerWg; c0 < count; c0 += (long long)p.groups * kWgRowsPerWg) {
+        const long long r0 = c0 + (long long)wave * kWgRowsPerWave;
+        const long long r1 = (r0 + kWgRowsPerWave < count) ? r0 + kWgRowsPerWave : count;        // multiples of 16; may be <= r0
+        for (long long r = r0; r < r1; r += 16) {
+            const size_t row0 = base + (size_t)r;
+            float x[8];
+            {
+                const f32x4 *xr = reinterpret_cast<const f32x4 *>(p.x + (row0 + j) * 32 + 8 * g);
+                const f32x4 v0 = xr[0], v1 = xr[1];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { x[c] = v0[c]; x[4 + c] = v1[c]; }
+            }
+            const float dz3v = p.dz3[(row0 + j) * 4 + g];
+            // the same features and the same dL/dz3 in the operand layout of the products (lane = 16 kk + column, register s = point 4 kk + s)
+            f32x4 xt[2], dz3t;
+#pragma unroll
+            for (int sidx = 0; sidx < 4; ++sidx) {
+                const size_t rr = row0 + 4 * g + sidx;
+                xt[0][sidx] = p.x[rr * 32 + j];
+                xt[1][sidx] = p.x[rr * 32 + 16 + j];
+                dz3t[sidx] = (j < 4) ? p.dz3[rr * 4 + j] : 0.0f;
+            }
+            f32x4 a1[4], a2[4], o, dz2[4], dz1[4];
+            float dxm[8];
+            mlp_tile_f32_keep(l_w, l_bias, x, lane, a1, a2, o);
+            mlp_bwd_tile_f32(l_wt, a1, a2, dz3v, lane, dz2, dz1, dxm);
+            (void)o; (void)dxm;
+#pragma unroll
+            for (int ob = 0; ob < 4; ++ob) { s2[ob] += dz2[ob]; s1[ob] += dz1[ob]; }
+            s3 += dz3v;
+            f32x4 ta[4], tb[4];
+            // dW3 = dZ3^T H2 (rows 4..15 of the A operand are zero)
+            wg_transpose(tt, a2, tb, lane);
+#pragma unroll
+            for (int sidx = 0; sidx < 4; ++sidx)
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb)
+                    acc3[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(dz3t[sidx], tb[cb][sidx], acc3[cb], 0, 0, 0);
+            // dW2 = dZ2^T H1
+            wg_transpose(tt, dz2, ta, lane);
+            wg_transpose(tt, a1, tb, lane);
+#pragma unroll
+            for (int sidx = 0; sidx < 4; ++sidx)
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                    for (int cb = 0; cb < 4; ++cb)
+                        acc2[mb * 4 + cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[mb][sidx], tb[cb][sidx], acc2[mb * 4 + cb], 0, 0, 0);
+            // dW1 = dZ1^T X
+            wg_transpose(tt, dz1, ta, lane);
+#pragma unroll
+            for (int sidx = 0; sidx < 4; ++sidx)
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb)
+                        acc1[mb * 2 + cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[mb][sidx], xt[cb][sidx], acc1[mb * 2 + cb], 0, 0, 0);
+        }
+    }
+    // bias gradients: sum over the 16 points of a lane row; the row's last lane holds units 16 ob + 4 g + r
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s2[ob][r] = row16_sum(s2[ob][r]); s1[ob][r] = row16_sum(s1[ob][r]); }
+    s3 = row16_sum(s3);
+    // the four waves add up in LDS (over the weights, which nobody needs any more), one after the other, then store once
+    __syncthreads();
+    float *red = lds;
     for (int w = 0; w < 4; ++w) {
         if (wave == w) {
             auto put = [&](int idx, float v) { red[idx] = (w == 0) ? v : red[idx] + v; };
@@ -701,18 +813,24 @@ __global__ __launch_bounds__(256) void weight_grad_partial_kernel(const WeightGr
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) put(kWgAcc3 + (t * 4 + q) * 64 + lane, acc3[t][q]);
+            if (j == 15) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) { put(kWgSum2 + c * 64 + lane, s2[c]); put(kWgSum1 + c * 64 + lane, s1[c]); }
-            put(kWgSum3 + lane, s3);
+                for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        put(kWgSum2 + 16 * ob + 4 * g + r, s2[ob][r]);
+                        put(kWgSum1 + 16 * ob + 4 * g + r, s1[ob][r]);
+                    }
+                put(kWgSum3 + g, s3);
+            }
         }
         __syncthreads();
     }
-    float *out = p.partial + ((size_t)b * p.chunks + chunk) * kWgPartial;
-    for (int i = threadIdx.x; i < kWgPartial; i += 256) out[i] = red[i];
+    float *out = p.partial + ((size_t)b * p.groups + grp) * kWgPartial;
+    for (int i = tid; i < kWgPartial; i += 256) out[i] = red[i];
 }
 
-// four threads per output element (64 elements per block): each sums every fourth partial that holds the element (and
-// undoes the operand permutation), then the four add up through LDS
+// four threads per output element (64 elements per block): each sums every fourth partial, then the four add up through LDS
 __global__ __launch_bounds__(256) void weight_grad_reduce_kernel(const WeightGradParams p) {
     __shared__ float red[256];
     const int el = threadIdx.x & 63, part4 = threadIdx.x >> 6;
@@ -720,43 +838,33 @@ __global__ __launch_bounds__(256) void weight_grad_reduce_kernel(const WeightGra
     constexpr int N2 = 64 * 64, N1 = 64 * 32, N3 = 4 * 64, NB = 64 + 64 + 4;
     const bool in_range = e < N2 + N1 + N3 + NB;
     const long long count = (long long)p.row_blocks[b] * 16;
-    const int valid = (int)((count + kWgRowsPerWg - 1) / kWgRowsPerWg);
-    const int nch = valid < p.chunks ? valid : p.chunks;
-    int idx[4] = {0, 0, 0, 0}, nidx = 1;
+    const long long chunks = (count + kWgRowsPerWg - 1) / kWgRowsPerWg;
+    const int nwg = chunks < p.groups ? (int)chunks : p.groups;      // workgroups that had a chunk and stored a partial
+    int idx = 0;
     float *dst = nullptr;
-    if (e < N2) {                       // dW2[m][c]: tile (m%4, c%4), register (m/4)%4, lane 16 (m/16) + c/4
+    // accumulator (mb, cb), register r, lane l  <->  row 16 mb + 4 (l >> 4) + r, column 16 cb + (l & 15)
+    if (e < N2) {
         const int m = e / 64, c = e % 64;
-        idx[0] = kWgAcc2 + (((m & 3) * 4 + (c & 3)) * 4 + ((m >> 2) & 3)) * 64 + 16 * (m >> 4) + (c >> 2);
+        idx = kWgAcc2 + (((m >> 4) * 4 + (c >> 4)) * 4 + (m & 3)) * 64 + 16 * ((m & 15) >> 2) + (c & 15);
         dst = p.dW2 + (size_t)b * N2 + e;
-    } else if (e < N2 + N1) {           // dW1[m][c]: tile (m%4, c%2), lane 16 (m/16) + c/2
+    } else if (e < N2 + N1) {
         const int f = e - N2, m = f / 32, c = f % 32;
-        idx[0] = kWgAcc1 + (((m & 3) * 2 + (c & 1)) * 4 + ((m >> 2) & 3)) * 64 + 16 * (m >> 4) + (c >> 1);
+        idx = kWgAcc1 + (((m >> 4) * 2 + (c >> 4)) * 4 + (m & 3)) * 64 + 16 * ((m & 15) >> 2) + (c & 15);
         dst = p.dW1 + (size_t)b * N1 + f;
-    } else if (e < N2 + N1 + N3) {      // dW3[o][c]: tile c%4, register o, lanes 0..15
+    } else if (e < N2 + N1 + N3) {      // rows 0..3 of the (zero-padded) 16-row product: lanes 0..15, register o
         const int f = e - N2 - N1, o = f / 64, c = f % 64;
-        idx[0] = kWgAcc3 + ((c & 3) * 4 + o) * 64 + (c >> 2);
+        idx = kWgAcc3 + ((c >> 4) * 4 + o) * 64 + (c & 15);
         dst = p.dW3 + (size_t)b * N3 + f;
-    } else if (in_range) {              // biases: column sums held by the four k-groups of lanes
+    } else if (in_range) {
         const int f = e - N2 - N1 - N3;
-        nidx = 4;
-        if (f < 64) {
-            for (int g = 0; g < 4; ++g) idx[g] = kWgSum1 + (f & 3) * 64 + 16 * g + (f >> 2);
-            dst = p.db1 + (size_t)b * 64 + f;
-        } else if (f < 128) {
-            const int c = f - 64;
-            for (int g = 0; g < 4; ++g) idx[g] = kWgSum2 + (c & 3) * 64 + 16 * g + (c >> 2);
-            dst = p.db2 + (size_t)b * 64 + c;
-        } else {
-            const int o = f - 128;
-            for (int g = 0; g < 4; ++g) idx[g] = kWgSum3 + 16 * g + o;
-            dst = p.db3 + (size_t)b * 4 + o;
-        }
+        if (f < 64) { idx = kWgSum1 + f; dst = p.db1 + (size_t)b * 64 + f; }
+        else if (f < 128) { idx = kWgSum2 + f - 64; dst = p.db2 + (size_t)b * 64 + f - 64; }
+        else { idx = kWgSum3 + f - 128; dst = p.db3 + (size_t)b * 4 + f - 128; }
     }
-    const float *part = p.partial + (size_t)b * p.chunks * kWgPartial;
+    const float *part = p.partial + (size_t)b * p.groups * kWgPartial;
     float acc = 0.0f;
     if (in_range)
-        for (int ch = part4; ch < nch; ch += 4)
-            for (int g = 0; g < nidx; ++g) acc += part[(size_t)ch * kWgPartial + idx[g]];
+        for (int w = part4; w < nwg; w += 4) acc += part[(size_t)w * kWgPartial + idx];
     red[threadIdx.x] = acc;
     __syncthreads();
     if (in_range && part4 == 0) *dst = ((red[el] + red[64 + el]) + red[128 + el]) + red[192 + el];
@@ -831,10 +939,10 @@ extern "C" int enarf_render_bwd(const enarf_render_bwd_args *args, enarf_stream_
     if (a.B <= 0 || a.n <= 0 || a.P <= 0 || a.P > ENARF_MAX_PARTS || a.H <= 0 || a.W <= 0)
         return host::fail(ENARF_ERR_ARG, "enarf_render_bwd: bad sizes");
     if (a.H >= (1 << 23) || a.W >= (1 << 23)) return host::fail(ENARF_ERR_UNSUPPORTED, "enarf_render_bwd: plane side >= 2^23");
+    if (a.H < 2 || a.W < 2) return host::fail(ENARF_ERR_UNSUPPORTED, "enarf_render_bwd: planes of %dx%d: at least 2x2 texels", a.H, a.W);
     if (a.Nf < 2 || a.Nf > kBwdMaxSamples) return host::fail(ENARF_ERR_UNSUPPORTED, "enarf_render_bwd: Nf=%d outside [2, %d]", a.Nf, kBwdMaxSamples);
     if (!a.image_coord || !a.inv_intrinsics || !a.parts || !a.canonical_pose || !a.feat_cl || !a.mask_planes || !a.mlp_pack ||
-        !a.bins || !a.grad_feat_cl || !a.grad_mask_planes || !a.rows_x || !a.rows_h1 || !a.rows_h2 || !a.rows_dz1 ||
-        !a.rows_dz2 || !a.rows_dz3 || !a.row_blocks || !a.workspace)
+        !a.bins || !a.grad_feat_cl || !a.grad_mask_planes || !a.rows_x || !a.rows_dz3 || !a.row_blocks || !a.workspace)
         return host::fail(ENARF_ERR_ARG, "enarf_render_bwd: null pointer");
     if (a.rows_per_image < enarf_render_bwd_rows_per_image(a.n, a.Nf))
         return host::fail(ENARF_ERR_ARG, "enarf_render_bwd: rows_per_image %lld < %lld", a.rows_per_image,
@@ -853,8 +961,8 @@ extern "C" int enarf_render_bwd(const enarf_render_bwd_args *args, enarf_stream_
     long long wgs = (long long)num_cus * kBwdWavesPerSimd;
     const long long total = (long long)a.B * a.n;
     if (wgs > total) wgs = total;
-    if (a.Nf > 64) hipLaunchKernelGGL(render_bwd_kernel<2>, dim3((unsigned)wgs), dim3(256), (size_t)bwd_lds_floats(a.P) * 4, st, a);
-    else hipLaunchKernelGGL(render_bwd_kernel<1>, dim3((unsigned)wgs), dim3(256), (size_t)bwd_lds_floats(a.P) * 4, st, a);
+    if (a.Nf > 64) hipLaunchKernelGGL(render_bwd_kernel<2>, dim3((unsigned)wgs), dim3(256), (size_t)bwd_lds_floats(a.P, 128) * 4, st, a);
+    else hipLaunchKernelGGL(render_bwd_kernel<1>, dim3((unsigned)wgs), dim3(256), (size_t)bwd_lds_floats(a.P, ENARF_BWD_NS_FIXED ? 128 : 64) * 4, st, a);
     return host::check_launch("enarf_render_bwd");
 }
 
@@ -869,8 +977,9 @@ extern "C" int enarf_query_bwd(const enarf_query_bwd_args *args, enarf_stream_t 
     if (a.B <= 0 || a.B > 65535 || a.N < 0 || a.P <= 0 || a.P > ENARF_MAX_PARTS || a.H <= 0 || a.W <= 0)
         return host::fail(ENARF_ERR_ARG, "enarf_query_bwd: bad sizes");
     if (a.H >= (1 << 23) || a.W >= (1 << 23)) return host::fail(ENARF_ERR_UNSUPPORTED, "enarf_query_bwd: plane side >= 2^23");
+    if (a.H < 2 || a.W < 2) return host::fail(ENARF_ERR_UNSUPPORTED, "enarf_query_bwd: planes of %dx%d: at least 2x2 texels", a.H, a.W);
     if (!a.points || !a.parts || !a.canonical_pose || !a.feat_cl || !a.mask_planes || !a.mlp_pack || !a.grad_feat_cl ||
-        !a.grad_mask_planes || !a.rows_x || !a.rows_h1 || !a.rows_h2 || !a.rows_dz1 || !a.rows_dz2 || !a.rows_dz3 || !a.row_blocks)
+        !a.grad_mask_planes || !a.rows_x || !a.rows_dz3 || !a.row_blocks)
         return host::fail(ENARF_ERR_ARG, "enarf_query_bwd: null pointer");
     if (a.rows_per_image < enarf_query_bwd_rows_per_image(a.N))
         return host::fail(ENARF_ERR_ARG, "enarf_query_bwd: rows_per_image %lld < %lld", a.rows_per_image,
@@ -884,7 +993,7 @@ extern "C" int enarf_query_bwd(const enarf_query_bwd_args *args, enarf_stream_t 
     const long long tiles = (a.N + 63) / 64;
     long long per_image = ((long long)num_cus * kBwdWavesPerSimd + a.B - 1) / a.B;
     if (per_image > tiles) per_image = tiles;
-    hipLaunchKernelGGL(query_bwd_kernel, dim3((unsigned)per_image, a.B), dim3(256), (size_t)bwd_lds_floats(a.P) * 4, st, a, tiles);
+    hipLaunchKernelGGL(query_bwd_kernel, dim3((unsigned)per_image, a.B), dim3(256), (size_t)bwd_lds_floats(a.P, 64) * 4, st, a, tiles);
     return host::check_launch("enarf_query_bwd");
 }
 
@@ -898,10 +1007,18 @@ extern "C" int enarf_triplane_unpack_add(const float *grad_feat_cl, float *grad_
     return host::check_launch("enarf_triplane_unpack_add");
 }
 
+// workgroups per image: about four per CU over the whole batch, never more than the image has 1024-row chunks
+static int weight_grad_groups(int B, long long rows_per_image) {
+    const long long chunks = (rows_per_image + kWgRowsPerWg - 1) / kWgRowsPerWg;
+    long long g = (1024 + B - 1) / B;
+    if (g > chunks) g = chunks;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
 extern "C" size_t enarf_weight_grad_workspace_bytes(int B, long long rows_per_image) {
     if (B <= 0 || rows_per_image <= 0) return 0;
-    const long long chunks = (rows_per_image + kWgRowsPerWg - 1) / kWgRowsPerWg;
-    return (size_t)B * (size_t)chunks * kWgPartial * sizeof(float);
+    return (size_t)B * (size_t)weight_grad_groups(B, rows_per_image) * kWgPartial * sizeof(float);
 }
 
 extern "C" int enarf_weight_grad(const enarf_weight_grad_args *args, enarf_stream_t stream) {
@@ -909,19 +1026,22 @@ extern "C" int enarf_weight_grad(const enarf_weight_grad_args *args, enarf_strea
     const enarf_weight_grad_args &a = *args;
     if (a.B <= 0 || a.B > 65535 || a.rows_per_image <= 0 || a.rows_per_image % 16 != 0)
         return host::fail(ENARF_ERR_ARG, "enarf_weight_grad: bad sizes (B=%d rows_per_image=%lld)", a.B, a.rows_per_image);
-    if (!a.rows_x || !a.rows_h1 || !a.rows_h2 || !a.rows_dz1 || !a.rows_dz2 || !a.rows_dz3 || !a.row_blocks || !a.workspace ||
-        !a.dW1 || !a.dW2 || !a.dW3 || !a.db1 || !a.db2 || !a.db3)
+    if (!a.rows_x || !a.rows_dz3 || !a.mlp_pack || !a.row_blocks || !a.workspace || !a.dW1 || !a.dW2 || !a.dW3 || !a.db1 || !a.db2 || !a.db3)
         return host::fail(ENARF_ERR_ARG, "enarf_weight_grad: null pointer");
     WeightGradParams p;
-    p.x = a.rows_x; p.h1 = a.rows_h1; p.h2 = a.rows_h2; p.dz1 = a.rows_dz1; p.dz2 = a.rows_dz2; p.dz3 = a.rows_dz3;
+    p.x = a.rows_x; p.dz3 = a.rows_dz3; p.pack = a.mlp_pack;
     p.rows_per_image = a.rows_per_image; p.row_blocks = a.row_blocks;
     p.partial = reinterpret_cast<float *>(a.workspace);
-    const long long chunks = (a.rows_per_image + kWgRowsPerWg - 1) / kWgRowsPerWg;
-    if (chunks > 0x3FFFFFFFll) return host::fail(ENARF_ERR_UNSUPPORTED, "enarf_weight_grad: too many rows");
-    p.chunks = (int)chunks;
+    p.groups = weight_grad_groups(a.B, a.rows_per_image);
     p.dW1 = a.dW1; p.dW2 = a.dW2; p.dW3 = a.dW3; p.db1 = a.db1; p.db2 = a.db2; p.db3 = a.db3;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(weight_grad_partial_kernel, dim3((unsigned)chunks, a.B), dim3(256), 0, st, p);
+    static bool attr_set = false;        // more than the default 64 KB of dynamic LDS
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(weight_grad_partial_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return host::fail((int)e, "enarf_weight_grad: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(weight_grad_partial_kernel, dim3((unsigned)p.groups, a.B), dim3(256), (size_t)kWgLdsFloats * 4, st, p);
     if (int rc = host::check_launch("enarf_weight_grad(partial)")) return rc;
     hipLaunchKernelGGL(weight_grad_reduce_kernel, dim3((64 * 64 + 64 * 32 + 4 * 64 + 132 + 63) / 64, a.B), dim3(256), 0, st, p);
     return host::check_launch("enarf_weight_grad(reduce)");

@@ -93,15 +93,20 @@ __global__ __launch_bounds__(256) void pack_kernel(const float *__restrict__ in,
 template <bool separate>
 __global__ __launch_bounds__(256) void sample_fwd_direct(const float *__restrict__ in, const float *__restrict__ grid,
                                                          float *__restrict__ out, int C, int H, int W, long long n,
-                                                         SamplerCfg cfg, const int *__restrict__ point_image) {
+                                                         SamplerCfg cfg, const int *__restrict__ point_image, int n_images) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     const int b = blockIdx.y;
     if (i >= n) return;
     const float *g = grid + ((size_t)b * n + i) * 3;
     const float c3[3] = {g[0], g[1], g[2]};
     const size_t hw = (size_t)H * W;
-    const float *inb = in + (size_t)(point_image ? point_image[i] : b) * 3 * C * hw;
+    const int bi = point_image ? point_image[i] : b;
     float *ob = out + (size_t)b * (separate ? 3 : 1) * C * n + i;
+    if ((unsigned)bi >= (unsigned)n_images) {      // an image id outside the batch samples nothing (the reference's
+        for (int c = 0; c < (separate ? 3 : 1) * C; ++c) ob[(size_t)c * n] = 0.0f;      // side-by-side planes: zero padding)
+        return;
+    }
+    const float *inb = in + (size_t)bi * 3 * C * hw;
     if (cfg.interp == ENARF_INTERP_BILINEAR) {
         Tap2D t[3];
 #pragma unroll
@@ -172,7 +177,8 @@ __global__ __launch_bounds__(256) void sample_fwd_cl(const float *__restrict__ c
 __global__ __launch_bounds__(256) void sample_bwd_direct(const float *__restrict__ gout, const float *__restrict__ in,
                                                          const float *__restrict__ grid, float *__restrict__ gin,
                                                          float *__restrict__ ggrid, int C, int H, int W, long long n,
-                                                         SamplerCfg cfg, int separate, const int *__restrict__ point_image) {
+                                                         SamplerCfg cfg, int separate, const int *__restrict__ point_image,
+                                                         int n_images) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     const int b = blockIdx.y;
     if (i >= n) return;
@@ -180,6 +186,13 @@ __global__ __launch_bounds__(256) void sample_bwd_direct(const float *__restrict
     const float c3[3] = {g[0], g[1], g[2]};
     const size_t hw = (size_t)H * W;
     const int bi = point_image ? point_image[i] : b;
+    if ((unsigned)bi >= (unsigned)n_images) {      // sampled nothing in the forward: no gradient to any plane or to the grid
+        if (ggrid) {
+            float *o = ggrid + ((size_t)b * n + i) * 3;
+            o[0] = 0.0f; o[1] = 0.0f; o[2] = 0.0f;
+        }
+        return;
+    }
     const float *inb = in + (size_t)bi * 3 * C * hw;
     float *ginb = gin ? gin + (size_t)bi * 3 * C * hw : nullptr;
     const float *go = gout + (size_t)b * (separate ? 3 : 1) * C * n + i;
@@ -450,7 +463,7 @@ extern "C" int enarf_triplane_sample_fwd(const float *input, const float *grid, 
         return host::check_launch("enarf_triplane_sample_fwd");
     }
     hipLaunchKernelGGL(sample_fwd_direct<false>, dim3((unsigned)((n_pts + 255) / 256), B), dim3(256), 0, st, input, grid, out,
-                       C, H, W, n_pts, cfg, (const int *)nullptr);
+                       C, H, W, n_pts, cfg, (const int *)nullptr, B);
     return host::check_launch("enarf_triplane_sample_fwd");
 }
 
@@ -471,9 +484,9 @@ extern "C" int enarf_triplane_sample_ex_fwd(const float *input, const float *gri
     const SamplerCfg cfg{interp, pad, align_corners ? 1 : 0};
     const dim3 grd((unsigned)((n_pts + 255) / 256), B);
     if (reduction == ENARF_PLANES_SEPARATE)
-        hipLaunchKernelGGL(sample_fwd_direct<true>, grd, dim3(256), 0, (hipStream_t)stream, input, grid, out, C, H, W, n_pts, cfg, point_image);
+        hipLaunchKernelGGL(sample_fwd_direct<true>, grd, dim3(256), 0, (hipStream_t)stream, input, grid, out, C, H, W, n_pts, cfg, point_image, n_images);
     else
-        hipLaunchKernelGGL(sample_fwd_direct<false>, grd, dim3(256), 0, (hipStream_t)stream, input, grid, out, C, H, W, n_pts, cfg, point_image);
+        hipLaunchKernelGGL(sample_fwd_direct<false>, grd, dim3(256), 0, (hipStream_t)stream, input, grid, out, C, H, W, n_pts, cfg, point_image, n_images);
     return host::check_launch("enarf_triplane_sample_ex_fwd");
 }
 
@@ -486,7 +499,7 @@ extern "C" int enarf_triplane_sample_ex_bwd(const float *grad_out, const float *
     if (n_pts == 0 || (!grad_input && !grad_grid)) return 0;
     const SamplerCfg cfg{interp, pad, align_corners ? 1 : 0};
     hipLaunchKernelGGL(sample_bwd_direct, dim3((unsigned)((n_pts + 255) / 256), B), dim3(256), 0, (hipStream_t)stream, grad_out,
-                       input, grid, grad_input, grad_grid, C, H, W, n_pts, cfg, reduction == ENARF_PLANES_SEPARATE ? 1 : 0, point_image);
+                       input, grid, grad_input, grad_grid, C, H, W, n_pts, cfg, reduction == ENARF_PLANES_SEPARATE ? 1 : 0, point_image, n_images);
     return host::check_launch("enarf_triplane_sample_ex_bwd");
 }
 
@@ -511,7 +524,7 @@ extern "C" int enarf_triplane_sample_bwd(const float *grad_out, const float *inp
         return grad_input ? enarf_triplane_unpack_add(gcl, grad_input, B, 3 * C, H, W, stream) : 0;
     }
     hipLaunchKernelGGL(sample_bwd_direct, dim3((unsigned)((n_pts + 255) / 256), B), dim3(256), 0, (hipStream_t)stream,
-                       grad_out, input, grid, grad_input, grad_grid, C, H, W, n_pts, cfg, 0, (const int *)nullptr);
+                       grad_out, input, grid, grad_input, grad_grid, C, H, W, n_pts, cfg, 0, (const int *)nullptr, B);
     return host::check_launch("enarf_triplane_sample_bwd");
 }
 

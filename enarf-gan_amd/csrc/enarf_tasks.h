@@ -536,30 +536,38 @@ __device__ __forceinline__ void publish_ray(const MarchCtx &M, unsigned *sw, int
 template <int MODE>
 __device__ __forceinline__ void drain_point(RenderArgsK a, const MarchCtx &M, float *lds, int lane) {
     volatile unsigned *vsh = M.sh;
-    if (vsh[SH_PENDING] == 0u) return;
-    if (wave_lds_cas(&M.sh[SH_SWITCHING], 0u, 1u, lane) != 0u) return;       // somebody else is at it
-    lds_acquire();
-    // the parked ray with the smallest id decides the image (the lists are in image order)
-    unsigned best = 0xFFFFFFFFu;
-    for (int s = 0; s < M.nslots; ++s)
-        if (vsh[SH_PENDFLAG + s]) best = min(best, (unsigned)M.slots[s * kSlotWords + SL_RID]);
-    if (best != 0xFFFFFFFFu) {
-        const int b = (int)(best / (uint32_t)a->n);
-        if ((unsigned)b != vsh[SH_CTXB]) {
-            stage_image<MODE>(a, lds, b, lane);
-            if (lane == 0) M.sh[SH_CTXB] = (unsigned)b;
-        }
-        lds_release();
-        for (int s = 0; s < M.nslots; ++s) {
-            unsigned *sw = M.slots + s * kSlotWords;
-            if (vsh[SH_PENDFLAG + s] && (int)(sw[SL_RID] / (uint32_t)a->n) == b) {
-                if (lane == 0) { M.sh[SH_PENDFLAG + s] = 0u; atomicAdd(&M.sh[SH_PENDING], 0xFFFFFFFFu); atomicAdd(&M.sh[SH_INFLIGHT], 1u); }
-                publish_ray(M, sw, lane);
+    // Looped: while this wave owns SH_SWITCHING another slot's ray may retire and its refill park a ray of yet another
+    // image; that wave's compare-and-swap below fails and it leaves, counting on the owner. So the owner looks again after
+    // giving the flag back (the other wave's token release precedes its failed CAS, hence this re-check sees count zero).
+    while (true) {
+        if (vsh[SH_PENDING] == 0u) return;
+        if (wave_lds_cas(&M.sh[SH_SWITCHING], 0u, 1u, lane) != 0u) return;       // somebody else is at it
+        lds_acquire();
+        // the parked ray with the smallest id decides the image (the lists are in image order)
+        unsigned best = 0xFFFFFFFFu;
+        for (int s = 0; s < M.nslots; ++s)
+            if (vsh[SH_PENDFLAG + s]) best = min(best, (unsigned)M.slots[s * kSlotWords + SL_RID]);
+        if (best != 0xFFFFFFFFu) {
+            const int b = (int)(best / (uint32_t)a->n);
+            if ((unsigned)b != vsh[SH_CTXB]) {
+                stage_image<MODE>(a, lds, b, lane);
+                if (lane == 0) M.sh[SH_CTXB] = (unsigned)b;
+            }
+            lds_release();
+            for (int s = 0; s < M.nslots; ++s) {
+                unsigned *sw = M.slots + s * kSlotWords;
+                if (vsh[SH_PENDFLAG + s] && (int)(sw[SL_RID] / (uint32_t)a->n) == b) {
+                    if (lane == 0) { M.sh[SH_PENDFLAG + s] = 0u; atomicAdd(&M.sh[SH_PENDING], 0xFFFFFFFFu); atomicAdd(&M.sh[SH_INFLIGHT], 1u); }
+                    publish_ray(M, sw, lane);
+                }
             }
         }
+        lds_release();
+        if (lane == 0) __hip_atomic_store(&M.sh[SH_SWITCHING], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        lds_release();
+        lds_acquire();
+        if (!(vsh[SH_INFLIGHT] == 0u && vsh[SH_PENDING] != 0u)) return;
     }
-    lds_release();
-    if (lane == 0) __hip_atomic_store(&M.sh[SH_SWITCHING], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 // give back a slot's in-flight token; the wave that takes the count to zero handles the drain point
@@ -581,7 +589,10 @@ __device__ __noinline__ unsigned refill_slot(RenderArgsK a, const MarchCtx M, Ta
     // only this function takes it away, so nothing is lost whichever of the two comes first)
     volatile unsigned *vst = sw + SL_NEXT_STATE;
     unsigned ahead = *vst;
-    while (ahead == 3u) { __builtin_amdgcn_s_sleep(2); ahead = *vst; }       // its pop is in flight: that IS our pop
+    // its pop is in flight: that IS our pop. (The popper always finishes - a queue atomic and two loads; the watchdog's
+    // SH_ERROR still releases this spin like every other wait of the kernel.)
+    while (ahead == 3u && reinterpret_cast<volatile unsigned *>(M.sh)[SH_ERROR] == 0u) { __builtin_amdgcn_s_sleep(2); ahead = *vst; }
+    if (ahead == 3u) ahead = 2u;          // the launch is being abandoned: end this chain
     if (ahead == 1u) {
         lds_acquire();
         rid = (int)sw[SL_NEXT_RID];
@@ -627,7 +638,7 @@ __device__ __noinline__ unsigned prefetch_next_ray(TaskQueue tq, unsigned *sw, i
 // the march: NW waves per workgroup, one workgroup per CU, `nslots` rays in flight
 // =================================================================================================================================
 template <int MODE, int SPL, int NW>
-__global__ __launch_bounds__(NW * 64, NW / 4) void march_kernel(const enarf_render_args a, int nslots) {
+__global__ __launch_bounds__(NW * 64, NW / 4) void march_kernel(const enarf_render_args a, int nslots, unsigned int *status) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int P = a.P, Nc = a.Nc, Nf = a.Nf;
@@ -765,6 +776,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void march_kernel(const enarf_rend
         if (++idle > kIdleLimit) {
             if (lane == 0) {
                 M.sh[SH_ERROR] = 1u;
+                // the host's sticky status word (pinned host memory, enarf_device_status): seen by every caller, counters or not
+                if (status) __hip_atomic_fetch_or(status, ENARF_STATUS_MARCH_WATCHDOG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 if (a.counters) atomicAdd(&a.counters[7], 1ull);
                 reinterpret_cast<unsigned int *>(reinterpret_cast<char *>(a.workspace) + ws_header_off(a.ws_epoch))[0] = 0xDEADu;
             }

@@ -581,13 +581,16 @@ def render_step_fwd(*args, **kw) -> RenderOutputs:
 def render_bwd(image_coord, inv_intrinsics, parts, canonical_pose, tri_nchw, feat_cl, mlp_pack, Nf, bins,
                g_color, g_mask, g_disparity=None, render_scale: float = 1.0, drop_invalid_rays: Optional[bool] = None,
                feat_grad_channel_last: bool = False, clamp_mask: bool = False, uniform_part_weight: bool = False,
-               multiply_density_with_weight: bool = False):
+               multiply_density_with_weight: bool = False, counters: Optional[torch.Tensor] = None):
     """Backward of render_fwd w.r.t. the tri-plane and the per-image demodulated MLP weights / biases.
 
     Returns (grad_tri (same batch as tri_nchw: 1 for a shared tri-plane), dW [3 x (B,out,in)], db [3 x (out,)]).
     feat_grad_channel_last: the feature-plane gradient stays channel-last (same shape as feat_cl) and is returned as a
     fourth value instead of being folded into grad_tri[:, :96] (for producers that emit channel-last planes).
-    The weight gradients are formed from the kernel's per-tile rows by enarf_weight_grad (own MFMA split-K kernels, no library GEMM, no host sync)."""
+    The weight gradients are formed by enarf_weight_grad from the kernel's compact per-tile rows (features in, dL/dz3 out:
+    it re-runs the MLP forward and backward on them; no library GEMM, no host sync).
+    counters: optional zeroed int64 tensor [8] on the device (enarf_render_bwd_args.counters: pairs, tiles, rays, 128-B
+    feature-gradient lines added, part-probability adds, gather rounds)."""
     lib = _lib.load()
     coord = _dev_f32(image_coord, "image_coord")
     B, n = coord.shape[0], coord.shape[-1]
@@ -623,36 +626,38 @@ def render_bwd(image_coord, inv_intrinsics, parts, canonical_pose, tri_nchw, fea
     a.g_color, a.g_mask, a.g_disparity = _p(gc), _p(gm), _p(gd)
     a.grad_feat_cl, a.grad_feat_batch_stride = _p(gfeat), fstride
     a.grad_mask_planes, a.grad_mask_batch_stride = grad_tri.data_ptr() + PLANE_CH * H * W * 4, mstride
-    a.rows_x, a.rows_h1, a.rows_h2 = _p(bufs["x"]), _p(bufs["h1"]), _p(bufs["h2"])
-    a.rows_dz1, a.rows_dz2, a.rows_dz3 = _p(bufs["dz1"]), _p(bufs["dz2"]), _p(bufs["dz3"])
+    a.rows_x, a.rows_dz3 = _p(bufs["x"]), _p(bufs["dz3"])
     a.rows_per_image, a.row_blocks = rows, _p(blocks)
     a.workspace = _p(_render_workspace(dev, B, n))
+    if counters is not None:
+        if counters.dtype != torch.int64 or counters.numel() < 8 or counters.device != dev:
+            raise ValueError("counters: an int64 tensor of 8 elements on the inputs' device")
+        a.counters = _p(counters)
     with _Epoch(dev, counted=False):      # the backward's set-up clears the headers itself and uses header 0
         _lib.check(lib.enarf_render_bwd(C.byref(a), _stream(dev)), "enarf_render_bwd")
     if not feat_grad_channel_last:
         _lib.check(lib.enarf_triplane_unpack_add(_p(gfeat), _p(grad_tri), grad_tri.shape[0], Ct, H, W, _stream(dev)),
                    "enarf_triplane_unpack_add")
-    dW, db = _weight_grad(bufs, blocks, B, rows, dev)
+    dW, db = _weight_grad(bufs, blocks, mlp_pack, B, rows, dev)
     if feat_grad_channel_last:
         return grad_tri, dW, db, gfeat
     return grad_tri, dW, db
 
 
 def _row_buffers(B: int, rows: int, dev: torch.device):
-    bufs = {k: torch.empty(B, rows, w, dtype=torch.float32, device=dev)
-            for k, w in (("x", 32), ("h1", 64), ("h2", 64), ("dz1", 64), ("dz2", 64), ("dz3", 4))}
+    bufs = {k: torch.empty(B, rows, w, dtype=torch.float32, device=dev) for k, w in (("x", 32), ("dz3", 4))}
     return bufs, torch.zeros(B, dtype=torch.int32, device=dev)
 
 
-def _weight_grad(bufs, blocks, B: int, rows: int, dev: torch.device):
-    """dW'_l = dZ_l^T H_{l-1} per image and db_l = column sums of dZ_l, from the rows a backward kernel exported."""
+def _weight_grad(bufs, blocks, mlp_pack, B: int, rows: int, dev: torch.device):
+    """dW'_l = dZ_l^T H_{l-1} per image and db_l = column sums of dZ_l, from the compact rows (x, dz3) a backward kernel
+    exported: enarf_weight_grad re-runs the MLP forward and backward on them."""
     lib = _lib.load()
     dW = [torch.empty(B, 64, 32, device=dev), torch.empty(B, 64, 64, device=dev), torch.empty(B, 4, 64, device=dev)]
     dbb = [torch.empty(B, 64, device=dev), torch.empty(B, 64, device=dev), torch.empty(B, 4, device=dev)]
     w = _lib.WeightGradArgs()
     w.B, w.rows_per_image, w.row_blocks = B, rows, _p(blocks)
-    w.rows_x, w.rows_h1, w.rows_h2 = _p(bufs["x"]), _p(bufs["h1"]), _p(bufs["h2"])
-    w.rows_dz1, w.rows_dz2, w.rows_dz3 = _p(bufs["dz1"]), _p(bufs["dz2"]), _p(bufs["dz3"])
+    w.rows_x, w.rows_dz3, w.mlp_pack = _p(bufs["x"]), _p(bufs["dz3"]), _p(mlp_pack)
     w.dW1, w.dW2, w.dW3 = _p(dW[0]), _p(dW[1]), _p(dW[2])
     w.db1, w.db2, w.db3 = _p(dbb[0]), _p(dbb[1]), _p(dbb[2])
     wws = torch.empty(int(lib.enarf_weight_grad_workspace_bytes(B, rows)) // 4, dtype=torch.float32, device=dev)
@@ -693,13 +698,12 @@ def query_bwd(points, parts, canonical_pose, tri_nchw, feat_cl, mlp_pack, g_dens
     a.g_density, a.g_color = (_p(gd) if N else None), (_p(gc) if N else None)
     a.grad_feat_cl, a.grad_feat_batch_stride = _p(gfeat), fstride
     a.grad_mask_planes, a.grad_mask_batch_stride = grad_tri.data_ptr() + PLANE_CH * H * W * 4, mstride
-    a.rows_x, a.rows_h1, a.rows_h2 = _p(bufs["x"]), _p(bufs["h1"]), _p(bufs["h2"])
-    a.rows_dz1, a.rows_dz2, a.rows_dz3 = _p(bufs["dz1"]), _p(bufs["dz2"]), _p(bufs["dz3"])
+    a.rows_x, a.rows_dz3 = _p(bufs["x"]), _p(bufs["dz3"])
     a.rows_per_image, a.row_blocks = rows, _p(blocks)
     _lib.check(lib.enarf_query_bwd(C.byref(a), _stream(dev)), "enarf_query_bwd")
     _lib.check(lib.enarf_triplane_unpack_add(_p(gfeat), _p(grad_tri), grad_tri.shape[0], Ct, H, W, _stream(dev)),
                "enarf_triplane_unpack_add")
-    dW, db = _weight_grad(bufs, blocks, B, rows, dev)
+    dW, db = _weight_grad(bufs, blocks, mlp_pack, B, rows, dev)
     return grad_tri, dW, db
 
 

@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define ENARF_ABI_VERSION 2
+#define ENARF_ABI_VERSION 3
 
 #define ENARF_ERR_ARG          (-1)   /* null pointer / non-positive size / bad enum */
 #define ENARF_ERR_UNSUPPORTED  (-2)   /* valid in the reference but not implemented here (message says what) */
@@ -56,6 +56,16 @@ typedef void *enarf_stream_t;
 int         enarf_abi_version(void);
 int         enarf_version(void);          /* the same number under the name SURVEY.md 8(b) lists */
 const char *enarf_last_error(void);
+
+/* Sticky status of the CURRENT device, written by kernels that had to give up on their work (the entry points themselves
+ * are asynchronous and have returned 0 long before). One word of pinned host memory per device: reading it costs no
+ * synchronisation and shows every launch that has completed; synchronise the stream first to cover a particular launch.
+ * clear != 0 resets the word after reading. Returns 0 and *flags (0 = nothing to report), or a hipError_t when the
+ * status word could not be set up. The reference has no counterpart: its kernels cannot give up (kernel.cu:245-246). */
+#define ENARF_STATUS_MARCH_WATCHDOG 1u   /* enarf_render_fwd / _step_fwd with the task march (ENARF_MARCH_TASK, or AUTO for
+                                            Nc / Nf > 64 at B == 1): a wave found no work for ~0.3 s although rays were in
+                                            flight and ended the launch; that launch's outputs are INCOMPLETE */
+int enarf_device_status(unsigned int *flags, int clear);
 
 /* ---------------------------------------------------------------------------------------------
  * a1. The TriplaneSampler operator.
@@ -271,8 +281,10 @@ int enarf_render_step_fwd(const enarf_prepare_args *prep, const float *tri_nchw,
  * custom backward (libraries/NeRF/activation.py:12-16). Nf <= 128. As in the reference, gradients flow through the FINE pass
  * only (the importance samples are not differentiable) and not into poses.
  *   enarf_render_bwd   d loss / d tri-plane (atomically accumulated into caller-zeroed buffers) and, per valid
- *                      16-sample tile, the rows (x, h1, h2, dz1, dz2, dz3) from which the caller forms the weight
- *                      gradients dW'_l = dZ_l^T H_{l-1} with enarf_weight_grad, per image.
+ *                      16-sample tile, 16 compact rows (x: the 32 gathered features, dz3: dL/d the 4 pre-activation
+ *                      outputs of the last layer) from which enarf_weight_grad forms the weight gradients
+ *                      dW'_l = dZ_l^T H_{l-1} per image by re-running the MLP forward and backward on them
+ *                      (144 B per sample; round 2 exported all six activation rows: 1 168 B per sample).
  *   enarf_prepare_bwd  d loss / d (conv.weight, modulation.weight, modulation.bias, z_rend) from dW' (the backward of
  *                      ModulatedConv1d's modulate + F.normalize), per image; the caller sums the shared parameters.
  *   enarf_triplane_unpack_add   grad_tri[:, :96] += channel-last gradient (inverse of enarf_triplane_pack).
@@ -289,10 +301,14 @@ typedef struct {
     const float *g_color, *g_mask, *g_disparity;   /* upstream gradients (B,3,n), (B,n), (B,n); NULL = zero */
     float *grad_feat_cl; long long grad_feat_batch_stride;      /* (B|1, 3, H, W, 32), zero-filled by the caller */
     float *grad_mask_planes; long long grad_mask_batch_stride;  /* &grad_tri[0][96][0][0], zero-filled by the caller */
-    float *rows_x, *rows_h1, *rows_h2, *rows_dz1, *rows_dz2, *rows_dz3;   /* (B, rows_per_image, 32|64|64|64|64|4) */
+    float *rows_x, *rows_dz3;             /* (B, rows_per_image, 32) and (B, rows_per_image, 4) */
     long long rows_per_image;             /* >= enarf_render_bwd_rows_per_image(n, Nf) */
     unsigned int *row_blocks;             /* device (B,): 16-row blocks written per image (zeroed by the call) */
     void *workspace;                      /* as enarf_render_fwd */
+    unsigned long long *counters;         /* optional device [8], zeroed by the caller: [0] valid (part, fine sample) pairs,
+                                             [1] 16-sample tiles taken through the MLP backward, [2] rays, [3] 128-B lines
+                                             added into the feature-plane gradient (float atomics, after on-chip merging),
+                                             [4] 4-byte adds into the part-probability gradient planes, [5] gather rounds */
     int clamp_mask, uniform_part_weight;  /* as in enarf_query_args (clamp_mask: straight-through gradient, sampling.py:46-47) */
     int multiply_density_with_weight;     /* nerf_params.multiply_density_with_triplane_wieght: the gradient also reaches the
                                              part probability that attains the maximum (models/narf.py:271-272) */
@@ -318,7 +334,7 @@ typedef struct {
     const float *g_color;                 /* (B, 3, N) or NULL */
     float *grad_feat_cl; long long grad_feat_batch_stride;      /* (B|1, 3, H, W, 32), zero-filled by the caller */
     float *grad_mask_planes; long long grad_mask_batch_stride;  /* &grad_tri[0][96][0][0], zero-filled by the caller */
-    float *rows_x, *rows_h1, *rows_h2, *rows_dz1, *rows_dz2, *rows_dz3;   /* (B, rows_per_image, 32|64|64|64|64|4) */
+    float *rows_x, *rows_dz3;             /* (B, rows_per_image, 32) and (B, rows_per_image, 4), as enarf_render_bwd_args */
     long long rows_per_image;             /* >= enarf_query_bwd_rows_per_image(N) */
     unsigned int *row_blocks;             /* device (B,): 16-row blocks written per image (zeroed by the call) */
     int clamp_mask, uniform_part_weight, multiply_density_with_weight;
@@ -326,14 +342,17 @@ typedef struct {
 long long enarf_query_bwd_rows_per_image(long long N);
 int enarf_query_bwd(const enarf_query_bwd_args *args, enarf_stream_t stream);
 
-/* Weight gradients of the per-image (demodulated) StyledMLP from the rows enarf_render_bwd exported:
- *   dW1 (B,64,32) = dZ1^T X, dW2 (B,64,64) = dZ2^T H1, dW3 (B,4,64) = dZ3^T H2, db_l (B, out) = column sums of dZ_l,
- * over the first 16 * row_blocks[b] rows of image b. Replaces autograd through conv1d(groups=B)
- * (libraries/custom_stylegan2/net.py:240-243) for the rendered samples. Deterministic (no atomics).
+/* Weight gradients of the per-image (demodulated) StyledMLP from the compact rows enarf_render_bwd / enarf_query_bwd
+ * exported: every 16-row tile is taken through the exact-fp32 MLP forward (X -> H1, H2) and backward (dZ3 -> dZ2, dZ1)
+ * again - the same code on the same operands as the kernel that exported it, so the same bits - and
+ *   dW1 (B,64,32) = dZ1^T X, dW2 (B,64,64) = dZ2^T H1, dW3 (B,4,64) = dZ3^T H2, db_l (B, out) = column sums of dZ_l
+ * accumulate in registers over the first 16 * row_blocks[b] rows of image b. Replaces autograd through
+ * conv1d(groups=B) (libraries/custom_stylegan2/net.py:240-243) for the rendered samples. Deterministic (no atomics).
  * workspace: enarf_weight_grad_workspace_bytes(B, rows_per_image) bytes of device memory. */
 typedef struct {
     int B;
-    const float *rows_x, *rows_h1, *rows_h2, *rows_dz1, *rows_dz2, *rows_dz3;   /* as enarf_render_bwd_args */
+    const float *rows_x, *rows_dz3;       /* as enarf_render_bwd_args */
+    const void *mlp_pack;                 /* the pack of the forward (enarf_prepare), B images */
     long long rows_per_image;
     const unsigned int *row_blocks;
     float *dW1, *dW2, *dW3, *db1, *db2, *db3;

@@ -27,7 +27,7 @@ def test_header_symbols_all_exported_and_bound():
         assert hasattr(lib, name), f"{name} declared in enarf_hip.h but not exported by libenarf_hip.so"
         assert name in _lib.SIGNATURES, f"{name} has no ctypes signature in _lib.py"
     assert set(_lib.SIGNATURES) == set(declared)
-    assert lib.enarf_abi_version() == _lib.ABI_VERSION == 2
+    assert lib.enarf_abi_version() == _lib.ABI_VERSION == 3
     assert lib.enarf_mlp_pack_bytes() % 16 == 0
 
 
@@ -40,7 +40,15 @@ def test_struct_layouts_match_the_header():
                                                     "fine_depth", "dbg_bins", "counters", "workspace", "clamp_mask",
                                                     "march", "ws_epoch"]),
               "enarf_query_args": ("QueryArgs", ["N", "P", "points", "mask_batch_stride", "dbg_weight"]),
-              "enarf_prepare_args": ("PrepareArgs", ["coordinate_scale", "parents", "pose_to_camera", "bias", "mlp_pack"])}
+              "enarf_prepare_args": ("PrepareArgs", ["coordinate_scale", "parents", "pose_to_camera", "bias", "mlp_pack"]),
+              "enarf_render_bwd_args": ("RenderBwdArgs", ["render_scale", "bins", "g_disparity", "grad_mask_batch_stride", "rows_x",
+                                                          "rows_dz3", "rows_per_image", "row_blocks", "workspace", "counters",
+                                                          "clamp_mask", "multiply_density_with_weight"]),
+              "enarf_query_bwd_args": ("QueryBwdArgs", ["N", "points", "g_color", "rows_x", "rows_dz3", "rows_per_image",
+                                                        "row_blocks", "multiply_density_with_weight"]),
+              "enarf_weight_grad_args": ("WeightGradArgs", ["rows_x", "rows_dz3", "mlp_pack", "rows_per_image", "row_blocks",
+                                                            "dW1", "db3", "workspace"]),
+              "enarf_prepare_bwd_args": ("PrepareBwdArgs", ["style_dim", "z_rend", "dW", "d_mod_bias", "d_z_rend"])}
     prog = ['#include "enarf_hip.h"', "#include <stdio.h>", "#include <stddef.h>", "int main(void){"]
     for cs, (_, fl) in fields.items():
         prog.append(f'printf("%zu\\n", sizeof({cs}));')
@@ -73,6 +81,12 @@ def test_argument_validation_needs_no_device():
     p.B, p.num_joints, p.style_dim, p.origin_location = 1, 24, 20, 7
     assert lib.enarf_prepare(C.byref(p), None) == -1 and b"origin_location" in lib.enarf_last_error()
     assert lib.enarf_triplane_sample_fwd(None, None, None, 1, 1, 1, 1, 1, 0, 0, 0, None, None) == -1
+    assert lib.enarf_device_status(None, 0) == -1 and b"flags is null" in lib.enarf_last_error()
+    a.P, a.H, a.W = 23, 256, 1          # a one-column plane: the part-probability taps are fetched as pairs of adjacent floats
+    assert lib.enarf_render_fwd(C.byref(a), None) == -2 and b"2x2" in lib.enarf_last_error()
+    w = _lib.WeightGradArgs()
+    w.B, w.rows_per_image = 1, 16
+    assert lib.enarf_weight_grad(C.byref(w), None) == -1 and b"null pointer" in lib.enarf_last_error()
     assert lib.enarf_triplane_sample_workspace_bytes(2, 32, 256, 256) == 2 * 3 * 32 * 256 * 256 * 4
     assert lib.enarf_triplane_sample_workspace_bytes(2, 5, 256, 256) == 0
 
