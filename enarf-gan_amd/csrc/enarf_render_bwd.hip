@@ -281,14 +281,26 @@ __device__ __forceinline__ void bwd_backward_tile(const QueryCtx &S, const BwdTi
         dot += quad_perm_f<0xB1>(dot);
         dot += quad_perm_f<0x4E>(dot);                                  // d loss / d w_k, quad-uniform
         if (act && k == kmax) dot += gwm;                               // density = MyReLU(.) * 10 * max_k w_k (narf.py:271-272)
-        {   // w = s0 s1 s2, s = sigmoid(m): dw/dm_g = w (1 - s_g); lane g adds into the four taps of its plane
-            const bool mon = act && g4 < 3 && !(ENARF_BWD_ABLATE & 2) && !(S.uniform_w > 0.0f);     // uniform weights: no plane gradient
-            const float gm = mon ? dot * wp * (1.0f - sg) : 0.0f;
-            const int pbase = (3 * k + g4) * (int)T.mplane;
-            mask_tap_add(T.gmask, mon && t.w00 != 0.0f, pbase + t.o00, t.w00 * gm, lane, C.mask_adds);
-            mask_tap_add(T.gmask, mon && t.w01 != 0.0f, pbase + t.o01, t.w01 * gm, lane, C.mask_adds);
-            mask_tap_add(T.gmask, mon && t.w10 != 0.0f, pbase + t.o10, t.w10 * gm, lane, C.mask_adds);
-            mask_tap_add(T.gmask, mon && t.w11 != 0.0f, pbase + t.o11, t.w11 * gm, lane, C.mask_adds);
+        {   // w = s0 s1 s2, s = sigmoid(m): dw/dm_p = w (1 - s_p) for plane p, spread over the plane's four taps.
+            // One wave-instruction per PLANE with lane = (quad, tap): the two taps of a row are adjacent floats in adjacent
+            // lanes, so they leave as ONE 64-byte request at the memory side, where the atomics are counted and paid for
+            // (round 2 issued one instruction per tap slot with lane = (quad, plane): every add its own request - 8.3 M of
+            // the 20.4 M requests of a C1 backward, profiles/r03_bwd_a_pmc_summary.txt)
+            const bool mon = act && !(ENARF_BWD_ABLATE & 2) && !(S.uniform_w > 0.0f);     // uniform weights: no plane gradient
+            const float gm = dot * wp * (1.0f - sg);                                       // lane g4 < 3: its own plane's
+#define ENARF_MASK_PLANE(PL)                                                                                                   \
+            {   /* all eight broadcasts run with the whole quad enabled (a DPP read of a disabled lane returns nothing) */        \
+                const int o0 = quad_bcast_i<PL>(t.o00), o1 = quad_bcast_i<PL>(t.o01), o2 = quad_bcast_i<PL>(t.o10), o3 = quad_bcast_i<PL>(t.o11); \
+                const float w0 = quad_bcast_f<PL>(t.w00), w1 = quad_bcast_f<PL>(t.w01), w2 = quad_bcast_f<PL>(t.w10), w3 = quad_bcast_f<PL>(t.w11); \
+                const float gp = quad_bcast_f<PL>(gm);                                                                         \
+                const int o = (g4 == 0) ? o0 : (g4 == 1) ? o1 : (g4 == 2) ? o2 : o3;                                           \
+                const float w = (g4 == 0) ? w0 : (g4 == 1) ? w1 : (g4 == 2) ? w2 : w3;                                         \
+                mask_tap_add(T.gmask, mon && w != 0.0f, (3 * k + PL) * (int)T.mplane + o, w * gp, lane, C.mask_adds);          \
+            }
+            ENARF_MASK_PLANE(0)
+            ENARF_MASK_PLANE(1)
+            ENARF_MASK_PLANE(2)
+#undef ENARF_MASK_PLANE
         }
         // every lane takes part (wave-uniform): inactive quads contribute empty rows
         scatter_plane(T.gfeat, T.ttile, t0, wk, act, dxg, lane, C.lines);

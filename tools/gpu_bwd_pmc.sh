@@ -1,13 +1,16 @@
 #!/bin/bash
 # profile evidence for the BACKWARD (profiles/r03_bwd_*): kernel-trace stats of tools/bench_bwd.py, then PMC groups in separate
-# passes (never combined with sys/hip traces). usage: tools/gpu_bwd_pmc.sh [OUTNAME]   env BATCH / DISTINCT / SIZE / NF as bench_bwd.py
+# passes (never combined with sys/hip traces). usage: tools/gpu_bwd_pmc.sh [OUTNAME]   env BATCH / DISTINCT / SIZE / NF as bench_bwd.py;
+# ONLY="stats atom" restricts the passes (default: all)
 NAME=${1:-pmc_bwd}
 mkdir -p gpurun_out/$NAME
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$NAME
-ITERS=20 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/tools/bench_bwd.py > $O/stats.log 2>&1
+want() { [ -z "$ONLY" ] || [[ " $ONLY " == *" $1 "* ]]; }
+want stats && ITERS=20 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/tools/bench_bwd.py > $O/stats.log 2>&1
 run() { n=$1; shift
+  want $n || return 0
   ITERS=3 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/$n -- python3 $R/tools/bench_bwd.py > $O/$n.log 2>&1
 }
 run sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD
