@@ -34,8 +34,9 @@ constexpr int SB_FH = 128;                                  // head [4][NS]
 __host__ __device__ constexpr int sb_fbits(int NS) { return SB_FH + 4 * NS; }          // bits [NS]
 __host__ __device__ constexpr int sb_dz3(int NS) { return sb_fbits(NS) + NS; }         // dL/dz3 [4][NS]
 __host__ __device__ constexpr int sb_wmax(int NS) { return sb_dz3(NS) + 4 * NS; }      // multiply_density_with_triplane_wieght: max part weight [NS]
-__host__ __device__ constexpr int sb_kmax(int NS) { return sb_wmax(NS) + NS; }         //   the part that attains it [NS] (ints)
-__host__ __device__ constexpr int sb_gwm(int NS) { return sb_kmax(NS) + NS; }          //   dL/d(max weight) [NS]
+__host__ __device__ constexpr int sb_kmax(int NS) { return sb_wmax(NS) + NS; }         //   the part that attains it [NS] (signed bytes: -1 .. 31;
+                                                                                       //   as ints the 128-sample layout was 192 B over two workgroups per CU)
+__host__ __device__ constexpr int sb_gwm(int NS) { return sb_kmax(NS) + NS / 4; }      //   dL/d(max weight) [NS]
 __host__ __device__ constexpr int sb_queue(int NS) { return sb_gwm(NS) + NS; }         // 2 ray slots
 __host__ __device__ constexpr int bwd_scratch_floats(int NS) { return sb_queue(NS) + 64; }
 static_assert(kQueueLdsInts <= 64, "scratch overflow");
@@ -358,7 +359,7 @@ __global__ __launch_bounds__(256, kBwdWavesPerSimd) void render_bwd_kernel(const
     int *l_cand = reinterpret_cast<int *>(scratch + SB_CAND) + wave * 32;
     float *l_fh = scratch + SB_FH, *l_dz3 = scratch + sb_dz3(NS);
     float *l_wmax = scratch + sb_wmax(NS), *l_gwm = scratch + sb_gwm(NS);
-    int *l_kmax = reinterpret_cast<int *>(scratch + sb_kmax(NS));
+    signed char *l_kmax = reinterpret_cast<signed char *>(scratch + sb_kmax(NS));
     float *ttile = scratch + bwd_scratch_floats(NS) + wave * kTTile;     // this wave's atomic-transpose tile
     uint32_t *l_fbits = reinterpret_cast<uint32_t *>(scratch + sb_fbits(NS));
     const int j4 = lane >> 2, g4 = lane & 3;
@@ -424,7 +425,7 @@ __global__ __launch_bounds__(256, kBwdWavesPerSimd) void render_bwd_kernel(const
                 const int io = base + lane;
                 l_fh[io] = o[0]; l_fh[NS + io] = o[1]; l_fh[2 * NS + io] = o[2]; l_fh[3 * NS + io] = o[3];
             }
-            if (i < Nf && g4 == 0) { l_fbits[i] = active ? bits[u] : 0u; l_wmax[i] = wmx; l_kmax[i] = kmx; }
+            if (i < Nf && g4 == 0) { l_fbits[i] = active ? bits[u] : 0u; l_wmax[i] = wmx; l_kmax[i] = (signed char)kmx; }
         }
         __syncthreads();
         const int next_ray = rq.get(qslot ^ 1);
@@ -523,7 +524,7 @@ __global__ __launch_bounds__(256, kBwdWavesPerSimd) void render_bwd_kernel(const
             const int ms = min(base + mj, Nf - 1);
             const float dz3v = (base + mj < Nf) ? l_dz3[mg * NS + ms] : 0.0f;
             const int si = min(base + j4, Nf - 1);             // gather layout: this quad's sample
-            bwd_backward_tile(S, T, b, px[u], py[u], pz[u], bits[u], a1, a2, x, dz3v, lane, C, l_gwm[si], l_kmax[si]);
+            bwd_backward_tile(S, T, b, px[u], py[u], pz[u], bits[u], a1, a2, x, dz3v, lane, C, l_gwm[si], (int)l_kmax[si]);
         }
         c_rays += 1;
         // the next ray's first barrier orders this ray's LDS reads (l_dz3, l_fh) before their next writes
@@ -565,7 +566,7 @@ __global__ __launch_bounds__(256, kBwdWavesPerSimd) void query_bwd_kernel(const 
     constexpr int NS = 64;
     float *l_fh = scratch + SB_FH, *l_dz3 = scratch + sb_dz3(NS);
     float *l_wmax = scratch + sb_wmax(NS), *l_gwm = scratch + sb_gwm(NS);
-    int *l_kmax = reinterpret_cast<int *>(scratch + sb_kmax(NS));
+    signed char *l_kmax = reinterpret_cast<signed char *>(scratch + sb_kmax(NS));
     uint32_t *l_fbits = reinterpret_cast<uint32_t *>(scratch + sb_fbits(NS));
     BwdTile T;
     T.H = a.H; T.W = a.W; T.mplane = (size_t)a.H * a.W; T.fplane = T.mplane * kFeat; T.l_wt = l_wt;
@@ -605,7 +606,7 @@ __global__ __launch_bounds__(256, kBwdWavesPerSimd) void query_bwd_kernel(const 
             const int io = wave * 16 + lane;
             l_fh[io] = o[0]; l_fh[64 + io] = o[1]; l_fh[128 + io] = o[2]; l_fh[192 + io] = o[3];
         }
-        if (g4 == 0) { l_fbits[wave * 16 + j4] = active ? bits : 0u; l_wmax[wave * 16 + j4] = wmx; l_kmax[wave * 16 + j4] = kmx; }
+        if (g4 == 0) { l_fbits[wave * 16 + j4] = active ? bits : 0u; l_wmax[wave * 16 + j4] = wmx; l_kmax[wave * 16 + j4] = (signed char)kmx; }
         __syncthreads();
         if (wave == 0) {   // head backward, lane = point of the tile
             const long long pi = tile * 64 + lane;
@@ -638,7 +639,7 @@ __global__ __launch_bounds__(256, kBwdWavesPerSimd) void query_bwd_kernel(const 
         if (ran) {
             const int mj = lane & 15, mg = lane >> 4;
             const float dz3v = l_dz3[mg * 64 + wave * 16 + mj];
-            bwd_backward_tile(S, T, b, px, py, pz, bits, a1, a2, x, dz3v, lane, C, l_gwm[wave * 16 + j4], l_kmax[wave * 16 + j4]);
+            bwd_backward_tile(S, T, b, px, py, pz, bits, a1, a2, x, dz3v, lane, C, l_gwm[wave * 16 + j4], (int)l_kmax[wave * 16 + j4]);
         }
         __syncthreads();     // l_fh / l_dz3 are rewritten by the next tile
     }
@@ -671,9 +672,8 @@ __global__ __launch_bounds__(256) void unpack_add_kernel(const float *__restrict
 // units 16 ob + 4 g + r): each 16 x 16 block is transposed through a wave-private LDS tile (4 ds_write_b32, 1 ds_read_b128)
 // into "lane = 16 kk + unit, register s = point 4 kk + s", which is both the A operand (rows = units of dZ) and the B operand
 // (columns = units of H) of v_mfma_f32_16x16x4_f32 with k-step s contracting points {s, 4 + s, 8 + s, 12 + s}.
-// A fixed number of workgroups per image strides over the image's 1024-row chunks and stores ONE partial each; a second
+// A fixed number of workgroups per image takes an even share of the image's tiles each and stores ONE partial; a second
 // kernel sums the partials in a fixed order. No atomics: deterministic for a given row order.
-constexpr int kWgRowsPerWave = 256, kWgRowsPerWg = 4 * kWgRowsPerWave;
 constexpr int kWgAcc2 = 0, kWgAcc1 = 16 * 256, kWgAcc3 = kWgAcc1 + 8 * 256, kWgSum2 = kWgAcc3 + 4 * 256;
 constexpr int kWgSum1 = kWgSum2 + 64, kWgSum3 = kWgSum1 + 64, kWgPartial = kWgSum3 + 16;      // floats per partial
 constexpr int kWgTStride = 20;                            // floats per unit row of the transpose tile (16 points + pad; rows stay 16-B aligned)
@@ -720,8 +720,12 @@ __global__ __launch_bounds__(256, 1) void weight_grad_partial_kernel(const Weigh
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.y;
     const int grp = blockIdx.x;
-    const long long count = (long long)p.row_blocks[b] * 16;
-    if ((long long)grp * kWgRowsPerWg >= count) return;      // block-uniform: this workgroup has no chunk
+    // the image's 16-row tiles are dealt evenly: workgroup grp of `groups` takes tiles [grp T / groups, (grp + 1) T / groups),
+    // its four waves a quarter each (a wave runs ~10 k cycles of MFMA per tile, so the launch is as long as its most loaded
+    // wave: fixed 1024-row chunks gave 460 busy workgroups for 256 CUs at C1, i.e. two rounds, 0.233 ms; even shares: one)
+    const long long tiles = (long long)p.row_blocks[b];
+    if (tiles == 0) return;                                   // block-uniform: the image exported nothing
+    const long long t_lo = tiles * grp / p.groups, t_hi = tiles * (grp + 1) / p.groups;
     float *l_w = lds, *l_bias = l_w + PK_B1, *l_wt = l_bias + 144, *tt = l_wt + PKT_FLOATS + wave * kWgTTile;
     {
         const float *pf = reinterpret_cast<const float *>(reinterpret_cast<const char *>(p.pack) + (size_t)b * kPackBytes);
@@ -742,9 +746,9 @@ __global__ __launch_bounds__(256, 1) void weight_grad_partial_kernel(const Weigh
 #pragma unroll
     for (int t = 0; t < 4; ++t) { acc3[t] = zero; s2[t] = zero; s1[t] = zero; }
     float s3 = 0.0f;
-    for (long long c0 = (long long)grp * kWgRowsPerWg; c0 < count; c0 += (long long)p.groups * kWgRowsPerWg) {
-        const long long r0 = c0 + (long long)wave * kWgRowsPerWave;
-        const long long r1 = (r0 + kWgRowsPerWave < count) ? r0 + kWgRowsPerWave : count;        // multiples of 16; may be <= r0
+    {
+        const long long nt = t_hi - t_lo;
+        const long long r0 = 16 * (t_lo + nt * wave / 4), r1 = 16 * (t_lo + nt * (wave + 1) / 4);
         for (long long r = r0; r < r1; r += 16) {
             const size_t row0 = base + (size_t)r;
             float x[8];
@@ -849,9 +853,7 @@ __global__ __launch_bounds__(256) void weight_grad_reduce_kernel(const WeightGra
     const int e = blockIdx.x * 64 + el, b = blockIdx.y;
     constexpr int N2 = 64 * 64, N1 = 64 * 32, N3 = 4 * 64, NB = 64 + 64 + 4;
     const bool in_range = e < N2 + N1 + N3 + NB;
-    const long long count = (long long)p.row_blocks[b] * 16;
-    const long long chunks = (count + kWgRowsPerWg - 1) / kWgRowsPerWg;
-    const int nwg = chunks < p.groups ? (int)chunks : p.groups;      // workgroups that had a chunk and stored a partial
+    const int nwg = p.row_blocks[b] ? p.groups : 0;       // every workgroup of an image that exported rows stored a partial
     int idx = 0;
     float *dst = nullptr;
     // accumulator (mb, cb), register r, lane l  <->  row 16 mb + 4 (l >> 4) + r, column 16 cb + (l & 15)
@@ -1019,11 +1021,13 @@ extern "C" int enarf_triplane_unpack_add(const float *grad_feat_cl, float *grad_
     return host::check_launch("enarf_triplane_unpack_add");
 }
 
-// workgroups per image: about four per CU over the whole batch, never more than the image has 1024-row chunks
+// workgroups per image: one workgroup per CU over the whole batch (the kernel holds 360 registers per lane: one wave per
+// SIMD), never more than the image can have 64-row shares
 static int weight_grad_groups(int B, long long rows_per_image) {
-    const long long chunks = (rows_per_image + kWgRowsPerWg - 1) / kWgRowsPerWg;
-    long long g = (1024 + B - 1) / B;
-    if (g > chunks) g = chunks;
+    const int cus = device_cus() > 0 ? device_cus() : 256;
+    long long g = (cus + B - 1) / B;
+    const long long most = (rows_per_image + 63) / 64;
+    if (g > most) g = most;
     if (g < 1) g = 1;
     return (int)g;
 }
