@@ -59,6 +59,9 @@ def parse():
     ap.add_argument("--cache-triplane", action="store_true", help="re-lay the (constant) tri-plane once instead of every step")
     ap.add_argument("--distinct-triplanes", action="store_true",
                     help="GAN style: one tri-plane per frame instead of one shared constant tri-plane (default at N > 1)")
+    ap.add_argument("--group-frames", type=int, default=0,
+                    help="frames per march launch for batches with per-frame tri-planes (enarf_render_args.group_frames): 0 = the "
+                         "library's choice (8), >= batch = one launch (round 2's behaviour); same results bit for bit")
     ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams the steps alternate over, each with its own intermediates; with 2 the pre-march launch of "
                          "step i+1 fills the CUs the persistent march of step i frees in its tail, but event-bracketed kernel "
@@ -211,7 +214,8 @@ def main():
                               3.0, coord, d["inv_intrinsics"], cpose_d, tri, f, Nc, Nf, parts_out=pa,
                               pack_out=pk, relayout=not args.cache_triplane, seed=seed, mlp_mode=mode or args.mlp_mode,
                               want_fine=True, count=count, early_stop_eps=args.early_stop_eps, return_bins=return_bins,
-                              march=args.march, drop_invalid_rays=True if args.drop_missed_rays else None)
+                              march=args.march, drop_invalid_rays=True if args.drop_missed_rays else None,
+                              group_frames=args.group_frames)
 
     # ---- the training step (opt-in): forward + backward + gradient all-reduce of the renderer's parameters
     train_params = None
@@ -295,6 +299,9 @@ def main():
                 o = bound_step(99 + i, k=i % n_streams).run()
                 if shard:
                     gather_outputs(o)
+    # per-frame tri-planes beyond one group of frames: the step is a sequence of (pre-march, march) pairs, see enarf_render.hip
+    gsize = args.group_frames if args.group_frames > 0 else 8
+    grouped = (not args.unfused) and tri.shape[0] > 1 and B > gsize
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     evf = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)] if args.train_step else None
@@ -314,10 +321,15 @@ def main():
             k = i % n_streams
             with torch.cuda.stream(streams[k]):
                 st = bound_step(99, k=k)
-                st.run(ops.STEP_PRE)
-                ev0[i].record()
-                o = st.run(ops.STEP_MARCH)
-                ev1[i].record()
+                if grouped:       # a batch marched in groups: pre-march and march alternate group by group (one call)
+                    ev0[i].record()
+                    o = st.run()
+                    ev1[i].record()
+                else:
+                    st.run(ops.STEP_PRE)
+                    ev0[i].record()
+                    o = st.run(ops.STEP_MARCH)
+                    ev1[i].record()
                 if shard:
                     gather_outputs(o)
             continue
@@ -338,6 +350,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
+    if grouped and not args.train_step:   # the marches alone, from a few extra steps with the two phases issued apart
+        ma, mb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        tot = 0.0
+        for _ in range(3):
+            st = bound_step(99)
+            st.run(ops.STEP_PRE)
+            ma.record()
+            st.run(ops.STEP_MARCH)
+            mb.record()
+            torch.cuda.synchronize()
+            tot += ma.elapsed_time(mb)
+        kern_ms = tot / 3
     backward = None
     if args.train_step:
         step_ms = kern_ms
@@ -434,6 +458,8 @@ def main():
         workload_key = f"C1:{S}:{B}:{Nc}:{Nf}:{P}:{args.mlp_mode}:{int(distinct)}:{args.early_stop_eps}"
         if args.march != "auto":
             workload_key += f":{args.march}"
+        if args.group_frames:
+            workload_key += f":g{args.group_frames}"
         # which of the two march kernels ran (enarf_render.hip launch_render: ENARF_MARCH_AUTO picks by shape)
         spl = 2 if (Nc > 64 or Nf > 64) else 1
         task = args.march == "task" or (args.march == "auto" and spl == 2 and B == 1)
@@ -491,6 +517,7 @@ def main():
                        "library": _lib.library_info(), "env": {k: v for k, v in os.environ.items() if k.startswith("ENARF_")},
                        "spinup_ms": args.spinup_ms, "streams": n_streams, "mlp_arith": args.mlp_mode, "march": args.march,
                        "early_stop_eps": args.early_stop_eps, "triplane_relayout_in_step": not args.cache_triplane,
+                       "group_frames": args.group_frames if args.group_frames else (8 if tri.shape[0] > 1 else 0),
                        "step": step_desc},
             "roofline": roof, "watchdog_counter": watchdog_counter,
         }

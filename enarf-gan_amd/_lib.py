@@ -81,6 +81,7 @@ class RenderArgs(C.Structure):
         ("dbg_coarse_density", _f32p), ("dbg_fine_density", _f32p), ("dbg_fine_color", _f32p),
         ("dbg_fine_valid", _f32p), ("dbg_bins", _f32p), ("counters", _f32p), ("workspace", _f32p),
         ("clamp_mask", C.c_int), ("uniform_part_weight", C.c_int), ("march", C.c_int), ("ws_epoch", C.c_int),
+        ("near_far", _f32p), ("ray_id_base", C.c_ulonglong), ("group_frames", C.c_int),
     ]
 
 
@@ -96,7 +97,7 @@ class RenderBwdArgs(C.Structure):
         ("grad_feat_cl", _f32p), ("grad_feat_batch_stride", C.c_longlong),
         ("grad_mask_planes", _f32p), ("grad_mask_batch_stride", C.c_longlong),
         ("rows_x", _f32p), ("rows_dz3", _f32p), ("rows_per_image", C.c_longlong), ("row_blocks", _f32p),
-        ("workspace", _f32p), ("counters", _f32p),
+        ("workspace", _f32p), ("near_far", _f32p), ("group_frames", C.c_int), ("counters", _f32p),
         ("clamp_mask", C.c_int), ("uniform_part_weight", C.c_int), ("multiply_density_with_weight", C.c_int),
     ]
 
@@ -157,6 +158,7 @@ SIGNATURES = {
     "enarf_mlp_unpack": (C.c_int, [C.c_void_p, _f32p, C.c_void_p]),
     "enarf_query_fwd": (C.c_int, [C.POINTER(QueryArgs), C.c_void_p]),
     "enarf_render_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "enarf_near_far": (C.c_int, [_f32p, C.c_int, C.c_int, _f32p, C.c_void_p]),
     "enarf_render_fwd": (C.c_int, [C.POINTER(RenderArgs), C.c_void_p]),
     "enarf_render_step_fwd": (C.c_int, [C.POINTER(PrepareArgs), _f32p, _f32p, C.c_int, C.c_int, C.POINTER(RenderArgs),
                                         C.c_int, C.c_void_p]),

@@ -236,4 +236,36 @@ struct RayQueue {
 int launch_ray_setup(const enarf_render_args &a, hipStream_t st);
 int device_cus();
 
+// ---- host: a batch with one tri-plane per frame is processed in groups of frames (enarf_render.hip, "marched in groups") --------
+constexpr int kDefaultGroupFrames = 8;
+constexpr size_t kWsGroupSlack = 32768;      // per frame: header pair + list rounding of a group's workspace slice (bound)
+
+struct GroupPlan {
+    int groups, base, extra;      // `extra` groups of base + 1 frames first, then groups of `base`
+    int first(int g) const { return g * base + (g < extra ? g : extra); }
+    int size(int g) const { return base + (g < extra ? 1 : 0); }
+};
+inline GroupPlan plan_groups(int B, long long feat_batch_stride, int group_frames) {
+    const int G = group_frames > 0 ? group_frames : kDefaultGroupFrames;
+    GroupPlan pl;
+    pl.groups = (feat_batch_stride == 0 || B <= G) ? 1 : (B + G - 1) / G;
+    pl.base = B / pl.groups;
+    pl.extra = B % pl.groups;
+    return pl;
+}
+inline size_t ws_slice_bytes(int nb, int n) { return (ws_total_bytes(nb, n) + 255) & ~(size_t)255; }
+// byte offset of group g's slice; the two near / far floats of a grouped call live behind the last slice
+inline size_t ws_slice_off(const GroupPlan &pl, int g, int n) {
+    const int big = g < pl.extra ? g : pl.extra;
+    return (size_t)big * ws_slice_bytes(pl.base + 1, n) + (size_t)(g - big) * ws_slice_bytes(pl.base, n);
+}
+
+template <typename T>
+inline T *off(T *p, long long elems) { return p ? p + elems : p; }
+
+// the two near / far floats of a grouped call: the last 256 bytes of the workspace
+inline float *ws_near_far_slot(void *workspace, int B, int n) {
+    return reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + enarf_render_workspace_bytes(B, n) - 256);
+}
+
 }  // namespace enarf

@@ -386,6 +386,41 @@ __device__ __forceinline__ float group_max(float v) {
 // enter the march; all others are appended to the live list in blocks that keep image order.
 constexpr int kSetupSmemFloats = ENARF_MAX_PARTS * kLdsPartStride + 32 + 12 + 5 * (kClasses + 1);
 
+// block of 256 threads: per-thread min / max of part-centre z -> l_red[8] = near, l_red[9] = far (rendering.py:15-17);
+// min and max are exact and order-free, so every spelling of the reduction gives the same two floats
+__device__ __forceinline__ void near_far_reduce(float mn, float mx, float *l_red, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    mn = wave_min(mn);
+    mx = wave_max(mx);
+    if (lane == 0) { l_red[wave] = mn; l_red[4 + wave] = mx; }
+    __syncthreads();
+    if (tid == 0) {
+#pragma clang fp contract(off)
+        const float zmin = fminf(fminf(l_red[0], l_red[1]), fminf(l_red[2], l_red[3]));
+        const float zmax = fmaxf(fmaxf(l_red[4], l_red[5]), fmaxf(l_red[6], l_red[7]));
+        l_red[8] = fmaxf(zmin - 1.7320508075688772f, 0.3f);
+        l_red[9] = fmaxf(zmax + 1.7320508075688772f, 5.0f);
+    }
+    __syncthreads();
+}
+// the planes of a whole batch, for launches that render it in pieces: from the part frames, or (RAW) from the raw poses
+// with the arithmetic of the part frames' z
+template <bool RAW>
+__global__ __launch_bounds__(256) void near_far_kernel(const float *__restrict__ parts, const enarf_prepare_args raw, int B, int P,
+                                                       float *__restrict__ out) {
+    __shared__ float l_red[12];
+    float mn = 3.0e38f, mx = -3.0e38f;
+    for (int i = threadIdx.x; i < B * P; i += 256) {
+        float z;
+        if constexpr (RAW) z = part_centre_z(raw, i / P, i % P);
+        else z = parts[(size_t)i * kPartStride + 11];
+        mn = fminf(mn, z);
+        mx = fmaxf(mx, z);
+    }
+    near_far_reduce(mn, mx, l_red, threadIdx.x);
+    if (threadIdx.x == 0) { out[0] = l_red[8]; out[1] = l_red[9]; }
+}
+
 // RAW: the part frames are computed here from the raw joint poses (same arithmetic as prepare_block, so the values
 // are bit-identical to a.parts) - lets set-up blocks run in the same launch as the prepare blocks. (`raw` stays a
 // reference to the kernel argument: taking its address would move the whole argument block to scratch.)
@@ -417,7 +452,10 @@ __device__ __forceinline__ void ray_setup_block(const enarf_render_args &a, cons
         for (int i = tid; i < P * kPartStride; i += 256)
             l_parts[(i / kPartStride) * kLdsPartStride + (i % kPartStride)] = a.parts[(size_t)b * P * kPartStride + i];
     }
-    {   // batch-global near / far planes (rendering.py:15-17): min / max of every part centre's z
+    if (a.near_far) {   // given by the caller: this launch renders a piece of a larger batch (block-uniform branch)
+        if (tid == 0) { l_red[8] = a.near_far[0]; l_red[9] = a.near_far[1]; }
+        __syncthreads();
+    } else {   // batch-global near / far planes (rendering.py:15-17): min / max of every part centre's z
         float mn = 3.0e38f, mx = -3.0e38f;
         for (int i = tid; i < a.B * P; i += 256) {
             float z;
@@ -426,18 +464,7 @@ __device__ __forceinline__ void ray_setup_block(const enarf_render_args &a, cons
             mn = fminf(mn, z);
             mx = fmaxf(mx, z);
         }
-        mn = wave_min(mn);
-        mx = wave_max(mx);
-        if (lane == 0) { l_red[wave] = mn; l_red[4 + wave] = mx; }
-        __syncthreads();
-        if (tid == 0) {
-#pragma clang fp contract(off)
-            const float zmin = fminf(fminf(l_red[0], l_red[1]), fminf(l_red[2], l_red[3]));
-            const float zmax = fmaxf(fmaxf(l_red[4], l_red[5]), fmaxf(l_red[6], l_red[7]));
-            l_red[8] = fmaxf(zmin - 1.7320508075688772f, 0.3f);
-            l_red[9] = fmaxf(zmax + 1.7320508075688772f, 5.0f);
-        }
-        __syncthreads();
+        near_far_reduce(mn, mx, l_red, tid);
     }
     const float near_p = l_red[8], far_p = l_red[9];
     if (tid < 32) l_dtab[tid] = linspace_sym(near_p, far_p, 32, tid);
@@ -740,7 +767,7 @@ __global__ __launch_bounds__(256, ENARF_RENDER_WAVES_PER_SIMD) void render_kerne
 #pragma unroll
             for (int s = 0; s < SPL; ++s) {
                 uint32_t rnd[4];
-                philox4x32(rid, 0u, (uint32_t)(64 * s + lane), 0x454E4152u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), rnd);
+                philox4x32((uint32_t)(a.ray_id_base + rid), (uint32_t)((a.ray_id_base + rid) >> 32), (uint32_t)(64 * s + lane), 0x454E4152u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), rnd);
                 esum[s] = (64 * s + lane < Nf) ? -__logf(1.0f - u32_to_unit(rnd[0])) : 0.0f;
                 if (s == 0) r1_first = rnd[1];
             }
@@ -1180,11 +1207,6 @@ static int launch_render(const enarf_render_args &a, hipStream_t st, bool with_s
     return host::check_launch("enarf_render_fwd");
 }
 
-extern "C" size_t enarf_render_workspace_bytes(int B, int n) {
-    if (B <= 0 || n <= 0) return 0;
-    return (ws_total_bytes(B, n) + 63) & ~(size_t)63;
-}
-
 static int check_render(const enarf_render_args &a) {
     if (int rc = check_common("enarf_render_fwd", a.B, a.P, a.H, a.W, a.mlp_mode, a.parts, a.canonical_pose, a.feat_cl,
                               a.mask_planes, a.mlp_pack)) return rc;
@@ -1212,10 +1234,106 @@ static int dispatch_march(const enarf_render_args &a, hipStream_t st, bool with_
     }
 }
 
+// ---- a batch with one tri-plane per frame is marched in groups of frames -------------------------------------------------------
+// 16 such frames in ONE launch march 14 % slower than two launches of 8 (profiles/r02_sweep.log: 68.7 M rays/s against
+// 79.7 M; 64 frames 61.5 M): with two or more frames per XCD band the lists interleave their rays, an XCD's 4 MB L2 serves two
+// frames' texels alternately (L2 hit rate 0.79 against 0.88, 9.0 GB of fabric traffic per launch against 0.83 GB compulsory)
+// and workgroups restage the MLP pack at every change of image. So the host cuts such a batch into groups of (by default) 8
+// frames - one frame per XCD - and issues one pre-march / march pair per group: views of the caller's arguments with offset
+// pointers, a queue header pair per group inside the workspace, the near / far planes reduced ONCE over the whole batch and
+// the sampler's ray ids counted batch-wide, so the results do not depend on the grouping, bit for bit.
+// frames [b0, b0 + nb) of a render call as a call of its own
+static enarf_render_args render_view(const enarf_render_args &a, int b0, int nb, void *ws, const float *near_far) {
+    enarf_render_args v = a;
+    const long long n = a.n, Nc = a.Nc, Nf = a.Nf;
+    v.B = nb;
+    v.image_coord = off(a.image_coord, b0 * 3 * n);
+    v.inv_intrinsics = off(a.inv_intrinsics, (long long)b0 * 9);
+    v.parts = off(a.parts, (long long)b0 * a.P * kPartStride);
+    v.feat_cl = off(a.feat_cl, b0 * a.feat_batch_stride);
+    v.mask_planes = off(a.mask_planes, b0 * a.mask_batch_stride);
+    v.mlp_pack = a.mlp_pack ? reinterpret_cast<const char *>(a.mlp_pack) + (size_t)b0 * kPackBytes : nullptr;
+    v.bins = off(a.bins, b0 * n * Nf);
+    v.color = off(a.color, b0 * 3 * n);
+    v.mask = off(a.mask, b0 * n);
+    v.disparity = off(a.disparity, b0 * n);
+    v.fine_weights = off(a.fine_weights, b0 * n * (Nf - 1));
+    v.fine_depth = off(a.fine_depth, b0 * n * Nf);
+    v.dbg_depth_min = off(a.dbg_depth_min, b0 * n);
+    v.dbg_depth_max = off(a.dbg_depth_max, b0 * n);
+    v.dbg_ray_valid = off(a.dbg_ray_valid, b0 * n);
+    v.dbg_coarse_density = off(a.dbg_coarse_density, b0 * n * Nc);
+    v.dbg_fine_density = off(a.dbg_fine_density, b0 * n * Nf);
+    v.dbg_fine_color = off(a.dbg_fine_color, b0 * 3 * n * Nf);
+    v.dbg_fine_valid = off(a.dbg_fine_valid, b0 * n * Nf);
+    v.dbg_bins = off(a.dbg_bins, b0 * n * Nf);
+    v.workspace = ws;
+    v.near_far = near_far;
+    v.ray_id_base = a.ray_id_base + (unsigned long long)b0 * (unsigned long long)n;
+    v.group_frames = nb;           // a view is one launch
+    return v;
+}
+static enarf_prepare_args prepare_view(const enarf_prepare_args &p, int b0, int nb, int P) {
+    enarf_prepare_args v = p;
+    v.B = nb;
+    v.pose_to_camera = off(p.pose_to_camera, (long long)b0 * p.num_joints * 16);
+    v.bone_length = off(p.bone_length, (long long)b0 * (p.num_joints - 1));
+    v.z_rend = off(p.z_rend, (long long)b0 * p.style_dim);
+    v.parts = off(p.parts, (long long)b0 * P * kPartStride);
+    v.mlp_pack = p.mlp_pack ? reinterpret_cast<char *>(p.mlp_pack) + (size_t)b0 * kPackBytes : nullptr;
+    return v;
+}
+
+extern "C" int enarf_near_far(const float *parts, int B, int P, float *out, enarf_stream_t stream) {
+    if (!parts || !out || B <= 0 || P <= 0 || P > ENARF_MAX_PARTS) return host::fail(ENARF_ERR_ARG, "enarf_near_far: bad arguments");
+    enarf_prepare_args unused = {};
+    hipLaunchKernelGGL(near_far_kernel<false>, dim3(1), dim3(256), 0, (hipStream_t)stream, parts, unused, B, P, out);
+    return host::check_launch("enarf_near_far");
+}
+
+extern "C" size_t enarf_render_workspace_bytes(int B, int n) {
+    if (B <= 0 || n <= 0) return 0;
+    // one launch, or any grouping of the B frames (a slice per group) + the near / far planes of a grouped call
+    return ((ws_total_bytes(B, n) + 255) & ~(size_t)255) + (size_t)B * kWsGroupSlack + 256;
+}
+static float *ws_near_far_slot(const enarf_render_args &a) { return ws_near_far_slot(a.workspace, a.B, a.n); }
+
 extern "C" int enarf_render_fwd(const enarf_render_args *args, enarf_stream_t stream) {
     if (!args) return host::fail(ENARF_ERR_ARG, "enarf_render_fwd: args is null");
     if (int rc = check_render(*args)) return rc;
-    return dispatch_march(*args, (hipStream_t)stream, true);
+    const enarf_render_args &a = *args;
+    hipStream_t st = (hipStream_t)stream;
+    const GroupPlan pl = plan_groups(a.B, a.feat_batch_stride, a.group_frames);
+    if (pl.groups == 1) return dispatch_march(a, st, true);
+    const float *nf = a.near_far;
+    if (!nf) {
+        float *slot = ws_near_far_slot(a);
+        if (int rc = enarf_near_far(a.parts, a.B, a.P, slot, stream)) return rc;
+        nf = slot;
+    }
+    for (int g = 0; g < pl.groups; ++g) {
+        const enarf_render_args v = render_view(a, pl.first(g), pl.size(g), reinterpret_cast<char *>(a.workspace) + ws_slice_off(pl, g, a.n), nf);
+        if (int rc = dispatch_march(v, st, true)) return rc;
+    }
+    return 0;
+}
+
+static int launch_pre_march(const enarf_prepare_args &p, const float *tri_nchw, float *feat_cl, int tri_B, int channels_total,
+                            const enarf_render_args &r, hipStream_t st) {
+    if (r.ws_epoch <= 0) {   // the caller does not count its calls: clear both headers with a fill
+        hipError_t e = hipMemsetAsync(r.workspace, 0, 2 * kWsHeaderBytes, st);
+        if (e != hipSuccess) return host::fail((int)e, "enarf_render_step_fwd: hipMemsetAsync(workspace) failed: %s", hipGetErrorString(e));
+    }
+    PreParams q;
+    q.prep = p; q.rend = r; q.tri = tri_nchw; q.feat_cl = feat_cl; q.tri_B = tri_B; q.ch_total = channels_total;
+    q.H = r.H; q.W = r.W;
+    q.n_pack = tri_nchw ? ((r.W + 63) / 64) * r.H * tri_B * 3 : 0;
+    q.n_prep = 3 * p.B;
+    q.bpi = ws_setup_blocks(r.n);
+    const long long blocks = (long long)q.n_pack + q.n_prep + (long long)q.bpi * r.B;
+    if (blocks > 0x7FFFFFFFll) return host::fail(ENARF_ERR_UNSUPPORTED, "enarf_render_step_fwd: too many blocks");
+    hipLaunchKernelGGL(pre_march_kernel, dim3((unsigned)blocks), dim3(256), 0, st, q);
+    return host::check_launch("enarf_render_step_fwd(pre-march)");
 }
 
 extern "C" int enarf_render_step_fwd(const enarf_prepare_args *prep, const float *tri_nchw, float *feat_cl, int tri_B,
@@ -1232,20 +1350,36 @@ extern "C" int enarf_render_step_fwd(const enarf_prepare_args *prep, const float
         return host::fail(ENARF_ERR_ARG, "enarf_render_step_fwd: bad tri-plane arguments");
     if (!(phases & ENARF_STEP_ALL) || (phases & ~ENARF_STEP_ALL)) return host::fail(ENARF_ERR_ARG, "enarf_render_step_fwd: bad phases %d", phases);
     hipStream_t st = (hipStream_t)stream;
-    if (!(phases & ENARF_STEP_PRE)) return dispatch_march(r, st, false);
-    if (r.ws_epoch <= 0) {   // the caller does not count its calls: clear both headers with a fill
-        hipError_t e = hipMemsetAsync(r.workspace, 0, 2 * kWsHeaderBytes, st);
-        if (e != hipSuccess) return host::fail((int)e, "enarf_render_step_fwd: hipMemsetAsync(workspace) failed: %s", hipGetErrorString(e));
+    const GroupPlan pl = plan_groups(r.B, r.feat_batch_stride, r.group_frames);
+    if (pl.groups == 1) {
+        if (phases & ENARF_STEP_PRE)
+            if (int rc = launch_pre_march(p, tri_nchw, feat_cl, tri_B, channels_total, r, st)) return rc;
+        return (phases & ENARF_STEP_MARCH) ? dispatch_march(r, st, false) : 0;
     }
-    PreParams q;
-    q.prep = p; q.rend = r; q.tri = tri_nchw; q.feat_cl = feat_cl; q.tri_B = tri_B; q.ch_total = channels_total;
-    q.H = r.H; q.W = r.W;
-    q.n_pack = tri_nchw ? ((r.W + 63) / 64) * r.H * tri_B * 3 : 0;
-    q.n_prep = 3 * p.B;
-    q.bpi = ws_setup_blocks(r.n);
-    const long long blocks = (long long)q.n_pack + q.n_prep + (long long)q.bpi * r.B;
-    if (blocks > 0x7FFFFFFFll) return host::fail(ENARF_ERR_UNSUPPORTED, "enarf_render_step_fwd: too many blocks");
-    hipLaunchKernelGGL(pre_march_kernel, dim3((unsigned)blocks), dim3(256), 0, st, q);
-    if (int rc = host::check_launch("enarf_render_step_fwd(pre-march)")) return rc;
-    return (phases & ENARF_STEP_MARCH) ? dispatch_march(r, st, false) : 0;
+    // groups of frames: per-frame tri-planes, so tri_B == B when the planes are re-laid here
+    if (tri_nchw && tri_B != r.B) return host::fail(ENARF_ERR_ARG, "enarf_render_step_fwd: %d tri-planes for a batch of %d frames with feat_batch_stride != 0", tri_B, r.B);
+    const float *nf = r.near_far;
+    if (!nf) {
+        float *slot = ws_near_far_slot(r);
+        if (phases & ENARF_STEP_PRE) {   // from the raw poses, in the arithmetic of the part frames (they are not written yet)
+            hipLaunchKernelGGL(near_far_kernel<true>, dim3(1), dim3(256), 0, st, (const float *)nullptr, p, r.B, P, slot);
+            if (int rc = host::check_launch("enarf_render_step_fwd(near / far)")) return rc;
+        }
+        nf = slot;                       // a march-only call finds what its pre-march call left there
+    }
+    const size_t tri_frame = (size_t)channels_total * r.H * r.W, cl_frame = (size_t)3 * r.H * r.W * kFeat;
+    // STEP_ALL: group by group (a group's freshly re-laid planes are still in the Infinity Cache when it is marched);
+    // a single phase: that phase for every group
+    for (int g = 0; g < pl.groups; ++g) {
+        const int b0 = pl.first(g), nb = pl.size(g);
+        const enarf_render_args v = render_view(r, b0, nb, reinterpret_cast<char *>(r.workspace) + ws_slice_off(pl, g, r.n), nf);
+        if (phases & ENARF_STEP_PRE) {
+            const enarf_prepare_args pv = prepare_view(p, b0, nb, P);
+            if (int rc = launch_pre_march(pv, tri_nchw ? tri_nchw + b0 * tri_frame : nullptr, feat_cl ? feat_cl + b0 * cl_frame : nullptr, nb,
+                                          channels_total, v, st)) return rc;
+        }
+        if (phases & ENARF_STEP_MARCH)
+            if (int rc = dispatch_march(v, st, false)) return rc;
+    }
+    return 0;
 }

@@ -947,6 +947,25 @@ extern "C" long long enarf_render_bwd_rows_per_image(int n, int Nf) {
     return (long long)n * (Nf > 64 ? 128 : 64);     // 16 rows per valid fine tile: 4 tiles per ray up to Nf 64, 8 up to 128
 }
 
+// ray set-up (own launch, epoch 0) + the backward kernel for one launch group
+static int launch_bwd_group(const enarf_render_bwd_args &a, hipStream_t st) {
+    enarf_render_args f = {};
+    f.B = a.B; f.n = a.n; f.P = a.P; f.Nc = 2; f.Nf = a.Nf; f.H = a.H; f.W = a.W;
+    f.drop_invalid_rays = a.drop_invalid_rays;
+    f.image_coord = a.image_coord; f.inv_intrinsics = a.inv_intrinsics; f.parts = a.parts;
+    f.workspace = a.workspace;                    // no outputs: the set-up only writes records and the live list
+    f.near_far = a.near_far;
+    if (int rc = launch_ray_setup(f, st)) return rc;
+    const int num_cus = device_cus();
+    if (num_cus <= 0) return host::fail((int)hipGetLastError(), "enarf_render_bwd: cannot query the device");
+    long long wgs = (long long)num_cus * kBwdWavesPerSimd;
+    const long long total = (long long)a.B * a.n;
+    if (wgs > total) wgs = total;
+    if (a.Nf > 64) hipLaunchKernelGGL(render_bwd_kernel<2>, dim3((unsigned)wgs), dim3(256), (size_t)bwd_lds_floats(a.P, 128) * 4, st, a);
+    else hipLaunchKernelGGL(render_bwd_kernel<1>, dim3((unsigned)wgs), dim3(256), (size_t)bwd_lds_floats(a.P, ENARF_BWD_NS_FIXED ? 128 : 64) * 4, st, a);
+    return host::check_launch("enarf_render_bwd");
+}
+
 extern "C" int enarf_render_bwd(const enarf_render_bwd_args *args, enarf_stream_t stream) {
     if (!args) return host::fail(ENARF_ERR_ARG, "enarf_render_bwd: args is null");
     const enarf_render_bwd_args &a = *args;
@@ -964,20 +983,40 @@ extern "C" int enarf_render_bwd(const enarf_render_bwd_args *args, enarf_stream_
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(a.row_blocks, 0, sizeof(unsigned int) * a.B, st);
     if (e != hipSuccess) return host::fail((int)e, "enarf_render_bwd: hipMemsetAsync failed: %s", hipGetErrorString(e));
-    enarf_render_args f = {};
-    f.B = a.B; f.n = a.n; f.P = a.P; f.Nc = 2; f.Nf = a.Nf; f.H = a.H; f.W = a.W;
-    f.drop_invalid_rays = a.drop_invalid_rays;
-    f.image_coord = a.image_coord; f.inv_intrinsics = a.inv_intrinsics; f.parts = a.parts;
-    f.workspace = a.workspace;                    // no outputs: the set-up only writes records and the live list
-    if (int rc = launch_ray_setup(f, st)) return rc;
-    const int num_cus = device_cus();
-    if (num_cus <= 0) return host::fail((int)hipGetLastError(), "enarf_render_bwd: cannot query the device");
-    long long wgs = (long long)num_cus * kBwdWavesPerSimd;
-    const long long total = (long long)a.B * a.n;
-    if (wgs > total) wgs = total;
-    if (a.Nf > 64) hipLaunchKernelGGL(render_bwd_kernel<2>, dim3((unsigned)wgs), dim3(256), (size_t)bwd_lds_floats(a.P, 128) * 4, st, a);
-    else hipLaunchKernelGGL(render_bwd_kernel<1>, dim3((unsigned)wgs), dim3(256), (size_t)bwd_lds_floats(a.P, ENARF_BWD_NS_FIXED ? 128 : 64) * 4, st, a);
-    return host::check_launch("enarf_render_bwd");
+    // per-frame tri-planes: groups of frames, as the forward (enarf_render.hip, "marched in groups") - one set-up + backward
+    // launch pair per group on views of the arguments, near / far reduced once over the whole batch
+    const GroupPlan pl = plan_groups(a.B, a.feat_batch_stride, a.group_frames);
+    if (pl.groups == 1) return launch_bwd_group(a, st);
+    const float *nf = a.near_far;
+    if (!nf) {
+        float *slot = ws_near_far_slot(a.workspace, a.B, a.n);
+        if (int rc = enarf_near_far(a.parts, a.B, a.P, slot, stream)) return rc;
+        nf = slot;
+    }
+    for (int g = 0; g < pl.groups; ++g) {
+        const long long b0 = pl.first(g), n = a.n;
+        enarf_render_bwd_args v = a;
+        v.B = pl.size(g);
+        v.image_coord = off(a.image_coord, b0 * 3 * n);
+        v.inv_intrinsics = off(a.inv_intrinsics, b0 * 9);
+        v.parts = off(a.parts, b0 * a.P * kPartStride);
+        v.feat_cl = off(a.feat_cl, b0 * a.feat_batch_stride);
+        v.mask_planes = off(a.mask_planes, b0 * a.mask_batch_stride);
+        v.mlp_pack = reinterpret_cast<const char *>(a.mlp_pack) + (size_t)b0 * kPackBytes;
+        v.bins = off(a.bins, b0 * n * a.Nf);
+        v.g_color = off(a.g_color, b0 * 3 * n);
+        v.g_mask = off(a.g_mask, b0 * n);
+        v.g_disparity = off(a.g_disparity, b0 * n);
+        v.grad_feat_cl = off(a.grad_feat_cl, b0 * a.grad_feat_batch_stride);
+        v.grad_mask_planes = off(a.grad_mask_planes, b0 * a.grad_mask_batch_stride);
+        v.rows_x = off(a.rows_x, b0 * a.rows_per_image * 32);
+        v.rows_dz3 = off(a.rows_dz3, b0 * a.rows_per_image * 4);
+        v.row_blocks = off(a.row_blocks, b0);
+        v.workspace = reinterpret_cast<char *>(a.workspace) + ws_slice_off(pl, g, a.n);
+        v.near_far = nf;
+        if (int rc = launch_bwd_group(v, st)) return rc;
+    }
+    return 0;
 }
 
 extern "C" long long enarf_query_bwd_rows_per_image(long long N) {

@@ -181,7 +181,7 @@ __device__ __forceinline__ void draw_sorted_uniforms(RenderArgsK a, uint32_t rid
 #pragma unroll
     for (int s = 0; s < SPL; ++s) {
         uint32_t rnd[4];
-        philox4x32(rid, 0u, (uint32_t)(64 * s + lane), 0x454E4152u, (uint32_t)a->seed, (uint32_t)(a->seed >> 32), rnd);
+        philox4x32((uint32_t)(a->ray_id_base + rid), (uint32_t)((a->ray_id_base + rid) >> 32), (uint32_t)(64 * s + lane), 0x454E4152u, (uint32_t)a->seed, (uint32_t)(a->seed >> 32), rnd);
         esum[s] = (64 * s + lane < Nf) ? -__logf(1.0f - u32_to_unit(rnd[0])) : 0.0f;
         if (s == 0) r1_first = rnd[1];
     }

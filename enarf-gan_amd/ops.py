@@ -413,23 +413,34 @@ def _render_workspace(dev: torch.device, B: int, n: int) -> torch.Tensor:
     return ws
 
 
+_render_shape = {}
+
+
 class _Epoch:
     """ws_epoch bookkeeping of the cached workspace of the current stream (include/enarf_hip.h, enarf_render_args):
-    `with _Epoch(dev) as k:` hands out the epoch for one forward call and, when the call went through, advances the
-    count; anything that raises - and every call that does not keep count, like the backward - falls back to epoch 0."""
+    `with _Epoch(dev, shape) as k:` hands out the epoch for one forward call and, when the call went through, advances the
+    count; anything that raises - and every call that does not keep count, like the backward - falls back to epoch 0, and
+    so does a call whose (B, n, group_frames, per-frame planes) differs from the previous one's: a batch marched in groups
+    keeps one queue-header pair per group inside the workspace, at offsets that depend on those."""
 
-    def __init__(self, dev: torch.device, counted: bool = True):
-        self.key, self.counted = _ws_key(dev), counted
+    def __init__(self, dev: torch.device, shape=None, counted: bool = True):
+        self.key, self.counted, self.shape = _ws_key(dev), counted, shape
 
     def __enter__(self) -> int:
-        self.k = _render_epoch.get(self.key, 0) if self.counted else 0
+        same = self.shape is not None and _render_shape.get(self.key) == self.shape
+        self.k = _render_epoch.get(self.key, 0) if (self.counted and same) else 0
         _render_epoch[self.key] = 0
+        _render_shape[self.key] = self.shape if self.counted else None
         return self.k
 
     def __exit__(self, exc_type, exc, tb):
         if exc_type is None:
             _render_epoch[self.key] = self.k + 1
         return False
+
+
+def _shape_key(a) -> tuple:
+    return (a.B, a.n, a.group_frames, a.feat_batch_stride != 0)
 
 
 class RenderOutputs:
@@ -443,14 +454,15 @@ def render_fwd(image_coord: torch.Tensor, inv_intrinsics: torch.Tensor, parts: t
                mlp_mode: str = "f32", multiply_density_with_weight: bool = False,
                drop_invalid_rays: Optional[bool] = None, want_fine: bool = True, debug: bool = False,
                count: bool = False, early_stop_eps: float = 0.0, return_bins: bool = False, clamp_mask: bool = False,
-               uniform_part_weight: bool = False, march: str = "auto") -> RenderOutputs:
+               uniform_part_weight: bool = False, march: str = "auto", group_frames: int = 0) -> RenderOutputs:
     """The fused ray march. image_coord (B,1,3,n) or (B,3,n); returns color (B,3,n), mask (B,n), disparity (B,n),
     fine_weights (B,1,n,Nf-1), fine_depth (B,1,n,Nf) and, with debug=True, the parity taps."""
     lib = _lib.load()
     a, o, _keep = _render_args(image_coord, inv_intrinsics, parts, canonical_pose, tri_nchw, feat_cl, mlp_pack, Nc, Nf,
                                render_scale, bins, seed, mlp_mode, multiply_density_with_weight, drop_invalid_rays,
                                want_fine, debug, count, early_stop_eps, return_bins, clamp_mask, uniform_part_weight, march)
-    with _Epoch(o.color.device) as k:
+    a.group_frames = int(group_frames)
+    with _Epoch(o.color.device, _shape_key(a)) as k:
         a.ws_epoch = k
         _lib.check(lib.enarf_render_fwd(C.byref(a), _stream(o.color.device)), "enarf_render_fwd")
     return o
@@ -532,7 +544,8 @@ class RenderStep:
                  coordinate_scale, image_coord, inv_intrinsics, canonical_pose, tri_nchw, feat_cl, Nc, Nf,
                  parts_out=None, pack_out=None, relayout=True, render_scale=1.0, bins=None, seed=0, mlp_mode="f32",
                  multiply_density_with_weight=False, drop_invalid_rays=None, want_fine=True, debug=False, count=False,
-                 early_stop_eps=0.0, return_bins=False, clamp_mask=False, uniform_part_weight=False, march="auto"):
+                 early_stop_eps=0.0, return_bins=False, clamp_mask=False, uniform_part_weight=False, march="auto",
+                 group_frames=0):
         self.lib = _lib.load()
         self.pa, k1, self.parts, self.pack = _prepare_args(pose_to_camera, bone_length, canonical_bone_length, z_rend,
                                                            mlp, parents, origin_location, coordinate_scale, parts_out,
@@ -541,6 +554,7 @@ class RenderStep:
                                              self.pack, Nc, Nf, render_scale, bins, seed, mlp_mode,
                                              multiply_density_with_weight, drop_invalid_rays, want_fine, debug, count,
                                              early_stop_eps, return_bins, clamp_mask, uniform_part_weight, march)
+        self.ra.group_frames = int(group_frames)
         self.tri = _dev_f32(tri_nchw, "tri_plane")
         self.feat_cl, self.relayout = feat_cl, relayout
         if feat_cl.shape[0] != self.tri.shape[0]:
@@ -562,7 +576,7 @@ class RenderStep:
             _lib.check(rc, "enarf_render_step_fwd")
 
         if phases & STEP_PRE:          # a new epoch starts with the pre-march phase; a march-only call stays in it
-            with _Epoch(t.device) as k:
+            with _Epoch(t.device, _shape_key(self.ra)) as k:
                 self.ra.ws_epoch = k
                 call()
         else:
@@ -581,7 +595,7 @@ def render_step_fwd(*args, **kw) -> RenderOutputs:
 def render_bwd(image_coord, inv_intrinsics, parts, canonical_pose, tri_nchw, feat_cl, mlp_pack, Nf, bins,
                g_color, g_mask, g_disparity=None, render_scale: float = 1.0, drop_invalid_rays: Optional[bool] = None,
                feat_grad_channel_last: bool = False, clamp_mask: bool = False, uniform_part_weight: bool = False,
-               multiply_density_with_weight: bool = False, counters: Optional[torch.Tensor] = None):
+               multiply_density_with_weight: bool = False, counters: Optional[torch.Tensor] = None, group_frames: int = 0):
     """Backward of render_fwd w.r.t. the tri-plane and the per-image demodulated MLP weights / biases.
 
     Returns (grad_tri (same batch as tri_nchw: 1 for a shared tri-plane), dW [3 x (B,out,in)], db [3 x (out,)]).
@@ -629,11 +643,12 @@ def render_bwd(image_coord, inv_intrinsics, parts, canonical_pose, tri_nchw, fea
     a.rows_x, a.rows_dz3 = _p(bufs["x"]), _p(bufs["dz3"])
     a.rows_per_image, a.row_blocks = rows, _p(blocks)
     a.workspace = _p(_render_workspace(dev, B, n))
+    a.group_frames = int(group_frames)
     if counters is not None:
         if counters.dtype != torch.int64 or counters.numel() < 8 or counters.device != dev:
             raise ValueError("counters: an int64 tensor of 8 elements on the inputs' device")
         a.counters = _p(counters)
-    with _Epoch(dev, counted=False):      # the backward's set-up clears the headers itself and uses header 0
+    with _Epoch(dev, counted=False):      # the backward's set-up clears the headers itself and uses header 0 (of every group)
         _lib.check(lib.enarf_render_bwd(C.byref(a), _stream(dev)), "enarf_render_bwd")
     if not feat_grad_channel_last:
         _lib.check(lib.enarf_triplane_unpack_add(_p(gfeat), _p(grad_tri), grad_tri.shape[0], Ct, H, W, _stream(dev)),

@@ -256,8 +256,27 @@ typedef struct {
                                              that used this workspace had ws_epoch k - 1 (any of enarf_render_fwd /
                                              enarf_render_step_fwd; enarf_render_bwd counts as epoch 0) and completed
                                              or is ordered before this one on the stream: that call left the header this
-                                             one uses clean, so no fill is launched. */
+                                             one uses clean, so no fill is launched. k > 0 also requires the same (B, n,
+                                             group_frames) as that previous call: a batch rendered in groups keeps one
+                                             queue header pair per group inside the workspace. */
+    /* ---- a batch rendered in several calls, or in several launches of one call ---- */
+    const float *near_far;                /* device [2] or NULL. The near / far planes are a reduction over the WHOLE batch
+                                             (rendering.py:15-17): NULL = reduce over this call's B frames; else the two
+                                             floats enarf_near_far wrote for the whole batch - for a caller that renders a
+                                             batch in pieces (ranks of a data-parallel job, groups of frames) */
+    unsigned long long ray_id_base;       /* added to b * n + ray in the in-kernel sampler's counter: first frame of this
+                                             call x n, so that a frame draws the same samples whichever call renders it */
+    int group_frames;                     /* frames per march launch when every frame has its own tri-plane
+                                             (feat_batch_stride != 0): 0 = the library's choice (8: one frame per XCD,
+                                             from measurements - 16 frames in one launch march 14 % slower than 2 x 8, the
+                                             XCDs' L2s then serve two frames' texels alternately), k > 0 = k, >= B = one
+                                             launch. Same results bit for bit for every value. */
 } enarf_render_args;
+
+/* near / far planes of a batch: out[0] = max(min_z - sqrt(3), 0.3), out[1] = max(max_z + sqrt(3), 5) over the z of every part
+ * centre of parts (B, P, 16) - the reduction decide_frustrum_range makes over the whole batch (rendering.py:15-17), in the
+ * same arithmetic as the ray set-up. out: device [2]. */
+int enarf_near_far(const float *parts, int B, int P, float *out, enarf_stream_t stream);
 
 size_t enarf_render_workspace_bytes(int B, int n);
 int enarf_render_fwd(const enarf_render_args *args, enarf_stream_t stream);
@@ -305,6 +324,8 @@ typedef struct {
     long long rows_per_image;             /* >= enarf_render_bwd_rows_per_image(n, Nf) */
     unsigned int *row_blocks;             /* device (B,): 16-row blocks written per image (zeroed by the call) */
     void *workspace;                      /* as enarf_render_fwd */
+    const float *near_far;                /* as enarf_render_args: NULL = reduce over this call's B frames */
+    int group_frames;                     /* as enarf_render_args (per-frame tri-planes: frames per launch; 0 = 8) */
     unsigned long long *counters;         /* optional device [8], zeroed by the caller: [0] valid (part, fine sample) pairs,
                                              [1] 16-sample tiles taken through the MLP backward, [2] rays, [3] 128-B lines
                                              added into the feature-plane gradient (float atomics, after on-chip merging),

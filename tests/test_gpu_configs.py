@@ -251,3 +251,59 @@ def test_mlp_arithmetic_modes_over_feature_scales(scale):
         out = ds.render(coord, 48, 32, bins, mlp_mode=mode)
         assert_close(_cpu(out.mask), rm, f"mask, features x {scale:g} [{mode}]")
         assert_close(_cpu(out.color), rc, f"colour, features x {scale:g} [{mode}]", tol)
+
+
+# ------------------------------------------------------------------------------------ batches marched in groups of frames
+def test_grouped_batch_gives_the_same_bits_as_one_launch():
+    """A batch with one tri-plane per frame is marched in groups of frames (enarf_render_args.group_frames, default 8: one
+    frame per XCD). The near / far planes are reduced once over the WHOLE batch (rendering.py:15-17) and the in-kernel
+    sampler counts its rays batch-wide, so every grouping gives the same bits as one launch: outputs, drawn bins and
+    counters, through enarf_render_fwd and through the fused enarf_render_step_fwd; the backward's gradients agree to the
+    rounding of their float atomics."""
+    from enarf_gan_amd import ops
+    S, B, Nc, Nf = 64, 12, 48, 32
+    sc = Scene(S, B, "center_fixed", 256)
+    ds = DeviceScene(sc)
+    s = dict(sc.raw)
+    s["pose_to_camera"] = s["pose_to_camera"].clone()
+    s["pose_to_camera"][7, :, 2, 3] += 3.0               # one frame far behind the others: it alone sets the far plane
+    d = ds.dev
+    # re-prepare with the moved frame
+    parts, pack = ops.prepare(s["pose_to_camera"].to(d), s["bone_length"].to(d), ds.sc.cbl.to(d), s["z_rend"].to(d), ds.mlp,
+                              s["parents"], ds.sc.ol, ds.sc.cs)
+    coord = s["image_coord"].to(d)
+
+    def render(g):
+        return ops.render_fwd(coord, ds.inv_K, parts, ds.cpose, ds.tri, ds.feat_cl, pack, Nc, Nf, seed=5, mlp_mode="f16x3",
+                              count=True, return_bins=True, group_frames=g)
+
+    one = render(B)
+    assert float(one.mask.max()) > 0.5
+    for g in (0, 5, 1):
+        o = render(g)
+        for name in ("color", "mask", "disparity", "fine_weights", "fine_depth"):
+            assert torch.equal(getattr(o, name), getattr(one, name)), (g, name)
+        assert torch.equal(o.taps["bins"], one.taps["bins"]) and torch.equal(o.counters, one.counters), g
+    # each group reducing near / far over its own frames would NOT give these bits: the far frame moves the planes
+    alone = ops.render_fwd(coord[:6], ds.inv_K[:6], parts[:6].contiguous(), ds.cpose, ds.tri[:6].contiguous(), ds.feat_cl[:6].contiguous(),
+                           pack[:6].contiguous(), Nc, Nf, seed=5, mlp_mode="f16x3")
+    assert not torch.equal(alone.fine_depth, one.fine_depth[:6])
+    # the fused step (re-layout + prepare + set-up in the pre-march launch of every group)
+    def step(g):
+        feat = torch.empty_like(ds.feat_cl)
+        st = ops.RenderStep(s["pose_to_camera"].to(d), s["bone_length"].to(d), ds.sc.cbl.to(d), s["z_rend"].to(d), ds.mlp,
+                            s["parents"], ds.sc.ol, ds.sc.cs, coord, ds.inv_K, ds.cpose, ds.tri, feat, Nc, Nf, seed=5,
+                            mlp_mode="f16x3", return_bins=True, group_frames=g)
+        return st.run()
+    s_one, s_grp = step(B), step(0)
+    assert torch.equal(s_one.mask, one.mask) and torch.equal(s_grp.mask, one.mask) and torch.equal(s_grp.color, one.color)
+    assert torch.equal(s_grp.taps["bins"], one.taps["bins"])
+    # backward: grouped against one launch
+    g = torch.Generator(device=d).manual_seed(1)
+    n = S * S
+    gc, gm = torch.randn(B, 3, n, device=d, generator=g), torch.randn(B, n, device=d, generator=g)
+    outs = [ops.render_bwd(coord, ds.inv_K, parts, ds.cpose, ds.tri, ds.feat_cl, pack, Nf, one.taps["bins"], gc, gm, group_frames=gf)
+            for gf in (B, 0)]
+    assert_close(outs[1][0].cpu(), outs[0][0].cpu(), "grad_tri, grouped backward", 2e-5)
+    for l in range(3):
+        assert_close(outs[1][1][l].cpu(), outs[0][1][l].cpu(), f"dW{l}, grouped backward", 2e-5)
