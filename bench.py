@@ -71,6 +71,9 @@ def parse():
     ap.add_argument("--train-step", action="store_true",
                     help="time forward + backward (enarf_render_bwd + weight gradients) + the gradient all-reduce "
                          "(sharding.all_reduce_gradients: constant tri-plane + StyledMLP parameters) instead of the forward alone")
+    ap.add_argument("--accum", type=int, default=2,
+                    help="--train-step: micro-batches per step (n_accum_step of configs/enarfgan_train/*/config.yml: 2); every "
+                         "micro-batch's gradient all-reduce overlaps the next one's forward and backward")
     ap.add_argument("--unfused", action="store_true", help="issue prepare / re-layout / render as the three separate C-ABI calls")
     ap.add_argument("--spinup-ms", type=float, default=40.0,
                     help="device spin-up during set-up, before the W warm-up steps (not part of W or K)")
@@ -180,11 +183,22 @@ def main():
     model = TriPlaneNARF(cfg, args.style_dim, 24, parent=sc["parents"], num_bone_param=23)
     model.register_canonical_pose(sc["canonical_pose"])
     cpose_d, cbl_d = model.canonical_pose.to(dev), model.canonical_bone_length.to(dev)
+    if multi:      # this rank's rows of the global batch's latents (poses are seeded per frame already)
+        sc["z_rend"] = synth.make_z_rend(world * B, args.style_dim)[first_frame:first_frame + B].contiguous()
     d = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in sc.items()}
     tri = sc["tri_plane"][:1].contiguous().to(dev)          # one constant tri-plane shared by the batch (DSO style)
-    if distinct:                                            # per-frame tri-planes: jittered copies, made on the device
-        g = torch.Generator(device=dev).manual_seed(5 + first_frame)
-        tri = (tri + 0.05 * torch.randn(B, *tri.shape[1:], device=dev, generator=g)).contiguous()
+
+    def frame_triplanes(base, first, count):
+        """per-frame tri-planes: jittered copies of the constant one, made on the device, seeded per FRAME of the global batch"""
+        out = torch.empty(count, *base.shape[1:], device=dev)
+        g = torch.Generator(device=dev)
+        for f in range(count):
+            g.manual_seed(5 + first + f)
+            out[f] = base[0] + 0.05 * torch.randn(*base.shape[1:], device=dev, generator=g)
+        return out
+
+    if distinct:
+        tri = frame_triplanes(tri, first_frame, B)
     mlp = {k: v.to(dev) for k, v in sc["mlp"].items()}
     coord = d["image_coord"].reshape(B, 3, n).contiguous()
     if shard:                                   # this rank's contiguous range of every frame's rays
@@ -208,51 +222,66 @@ def main():
     feat_cl, parts, pack = sets[0]
     torch.cuda.synchronize()
 
-    def bound_step(seed, count=False, k=0, mode=None, return_bins=False):
+    def bound_step(seed, count=False, k=0, mode=None, return_bins=False, frames=None):
+        """one forward step bound to its arguments; frames: a slice of this rank's frames (micro-batches of --train-step)"""
         f, pa, pk = sets[k]
-        return ops.RenderStep(d["pose_to_camera"], d["bone_length"], cbl_d, d["z_rend"], mlp, sc["parents"], args.origin,
-                              3.0, coord, d["inv_intrinsics"], cpose_d, tri, f, Nc, Nf, parts_out=pa,
-                              pack_out=pk, relayout=not args.cache_triplane, seed=seed, mlp_mode=mode or args.mlp_mode,
+        fs = slice(None) if frames is None else frames
+        ts = fs if tri.shape[0] > 1 else slice(None)          # a shared tri-plane is not sliced
+        return ops.RenderStep(d["pose_to_camera"][fs], d["bone_length"][fs], cbl_d, d["z_rend"][fs], mlp, sc["parents"], args.origin,
+                              3.0, coord[fs], d["inv_intrinsics"][fs], cpose_d, tri[ts], f[ts], Nc, Nf, parts_out=pa[fs],
+                              pack_out=pk[fs], relayout=not args.cache_triplane, seed=seed, mlp_mode=mode or args.mlp_mode,
                               want_fine=True, count=count, early_stop_eps=args.early_stop_eps, return_bins=return_bins,
                               march=args.march, drop_invalid_rays=True if args.drop_missed_rays else None,
                               group_frames=args.group_frames)
 
-    # ---- the training step (opt-in): forward + backward + gradient all-reduce of the renderer's parameters
+    # ---- the training step (opt-in): n_accum micro-batches of forward + backward; every micro-batch's gradients start their
+    # all-reduce (N > 1) as soon as its backward is enqueued and travel while the next micro-batch computes
     train_params = None
     if args.train_step:
         if Nf > 128:
             raise SystemExit("--train-step: the backward handles Nf <= 128")
+        n_accum = max(1, min(args.accum, B))
+        if B % n_accum:
+            raise SystemExit(f"--accum {n_accum} does not divide {B} frames per GPU")
         tri_param = torch.nn.Parameter(tri.clone())
         mlp_params = {k: torch.nn.Parameter(v.clone()) for k, v in mlp.items() if "noise" not in k}
-        train_params = [tri_param] + [mlp_params[k] for k in sorted(mlp_params)]
+        # a per-frame tri-plane is an activation of the (un-vendored) synthesis network, not a parameter: its gradient stays
+        # on the rank; a shared constant tri-plane (DSO style) is a parameter and is reduced with the StyledMLP's
+        train_params = ([] if distinct else [tri_param]) + [mlp_params[k] for k in sorted(mlp_params)]
         g_color = torch.randn(B, 3, n, device=dev)
         g_mask = torch.randn(B, n, device=dev)
+        reducer = sharding.GradientReducer(train_params, world) if dist is not None else None
+        local_tri_grads = [None] * n_accum
 
     def train_step(i, ev=None, counters=None):
-        """forward + backward of the renderer + (N > 1) the gradient all-reduce; ev = (after forward, after backward, before the march)"""
-        st = bound_step(99 + i, return_bins=True)
-        st.run(ops.STEP_PRE)
-        if ev:
-            ev[2].record()
-        o = st.run(ops.STEP_MARCH)
-        if ev:
-            ev[0].record()
-        grad_tri, dW, db = ops.render_bwd(coord, d["inv_intrinsics"], st.parts, cpose_d, tri, st.feat_cl, st.pack, Nf,
-                                          o.taps["bins"], g_color, g_mask, counters=counters)
-        pg, dz = ops.prepare_bwd(d["z_rend"], mlp, dW)
-        if ev:
-            ev[1].record()
-        train_params[0].grad = grad_tri
-        for kname in sorted(mlp_params):
-            leaf = kname.split(".", 2)[2]
-            layer = int(kname.split(".")[1])
-            mlp_params[kname].grad = (db[layer].reshape(mlp_params[kname].shape) if leaf == "bias"
-                                      else pg[kname].reshape(mlp_params[kname].shape))
-        if dist is not None:
-            # a per-frame tri-plane is an activation of the (un-vendored) synthesis network, not a parameter: its gradient
-            # stays on the rank; a shared constant tri-plane (DSO style) is a parameter and is reduced with the StyledMLP's
-            sharding.all_reduce_gradients(train_params[1:] if distinct else train_params, world)
-        return o
+        """ev: per micro-batch (before the march, after the forward, after the backward) events"""
+        per = B // n_accum
+
+        def backward_of(mb):
+            fs = slice(mb * per, (mb + 1) * per)
+            ts = fs if distinct else slice(None)
+            st = bound_step(99 + i, return_bins=True, frames=fs)
+            st.run(ops.STEP_PRE)
+            if ev:
+                ev[mb][0].record()
+            o = st.run(ops.STEP_MARCH)
+            if ev:
+                ev[mb][1].record()
+            grad_tri, dW, db = ops.render_bwd(coord[fs], d["inv_intrinsics"][fs], st.parts, cpose_d, tri[ts], st.feat_cl, st.pack, Nf,
+                                              o.taps["bins"], g_color[fs], g_mask[fs], counters=counters,
+                                              group_frames=args.group_frames)
+            pg, dz = ops.prepare_bwd(d["z_rend"][fs], mlp, dW)
+            if ev:
+                ev[mb][2].record()
+            grads = [] if distinct else [grad_tri]
+            local_tri_grads[mb] = grad_tri if distinct else None
+            for kname in sorted(mlp_params):
+                leaf = kname.split(".", 2)[2]
+                layer = int(kname.split(".")[1])
+                grads.append((db[layer] if leaf == "bias" else pg[kname]).reshape(mlp_params[kname].shape))
+            return grads
+
+        sharding.accumulate_and_reduce(range(n_accum), backward_of, train_params, reducer)
 
     def step(i, count=False):
         if args.train_step:
@@ -304,9 +333,7 @@ def main():
     grouped = (not args.unfused) and tri.shape[0] > 1 and B > gsize
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    evf = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)] if args.train_step else None
-    evb = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)] if args.train_step else None
-    evm = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)] if args.train_step else None
+    evt = [[[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(n_accum)] for _ in range(args.steps)] if args.train_step else None
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -314,7 +341,7 @@ def main():
     for i in range(args.steps):
         if args.train_step:
             ev0[i].record()
-            train_step(i, ev=(evf[i], evb[i], evm[i]))
+            train_step(i, ev=evt[i])
             ev1[i].record()
             continue
         if not args.unfused:      # same two launches as enarf_render_step_fwd(ENARF_STEP_ALL), with the march bracketed
@@ -365,13 +392,17 @@ def main():
     backward = None
     if args.train_step:
         step_ms = kern_ms
-        kern_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(evm, evf)]))      # the march alone, as in the forward-only bench
-        fwd_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, evf)]))
-        bwd_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(evf, evb)]))
+        # sums over the step's micro-batches: the marches alone (as in the forward-only bench), and the backward portions
+        kern_ms = float(np.mean([sum(m[0].elapsed_time(m[1]) for m in st_) for st_ in evt]))
+        bwd_ms = float(np.mean([sum(m[1].elapsed_time(m[2]) for m in st_) for st_ in evt]))
+        fwd_ms = float(np.mean([ev0[i].elapsed_time(evt[i][0][1]) + sum(evt[i][k - 1][2].elapsed_time(evt[i][k][1]) for k in range(1, n_accum))
+                                for i in range(args.steps)]))
         pairs, tiles, rays_b, lines, madds = bwd_cnt[:5]
         atomic_bytes = lines * 128 + madds * 4
         backward = {
-            "what": "enarf_render_bwd + enarf_triplane_unpack_add + enarf_weight_grad + enarf_prepare_bwd, events on the launch stream",
+            "what": "enarf_render_bwd + enarf_triplane_unpack_add + enarf_weight_grad + enarf_prepare_bwd, events on the launch stream, "
+                    f"summed over the step's {n_accum} micro-batch(es)",
+            "micro_batches": n_accum,
             "ms_per_step": bwd_ms, "forward_ms_per_step": fwd_ms, "collective_and_rest_ms_per_step": max(step_ms - fwd_ms - bwd_ms, 0.0),
             "valid_part_fine_sample_pairs": pairs, "mlp_backward_tiles_of_16": tiles, "rays": rays_b,
             "feature_gradient_lines_added_128B": lines, "part_probability_adds_4B": madds,
@@ -445,6 +476,40 @@ def main():
         p24 = {"workload": f"the same step with origin_location center+head (P = {sc2['num_parts']})", "value": B * n * args.steps / dt,
                "unit": "rays/s", "ms_per_step": dt / args.steps * 1e3}
 
+    one_gpu_same_job = None
+    if multi and rank == 0 and not args.train_step and not args.unfused:
+        # The N > 1 line is a different job from the N = 1 headline (C3's 64 frames against one C1 frame): here rank 0 alone
+        # renders the WHOLE global batch, so that the line carries its own one-GPU reference (the other ranks wait at the
+        # barrier below). Same frames (pose and tri-plane seeds are per frame of the global batch); one difference, named in
+        # the record: one process reduces the near / far planes over all 64 frames, a rank over its own share - which is what
+        # DistributedDataParallel does to the reference (every replica renders its own mini-batch, rendering.py:15-17).
+        GB = world * B
+        scg = synth.make_scene(S, GB, args.origin, args.style_dim, pose_seed=1234, shared_triplane=True)
+        dg = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in scg.items()}
+        trig = frame_triplanes(sc["tri_plane"][:1].contiguous().to(dev), 0, GB)
+        fg = torch.empty(GB, 3, 256, 256, 32, device=dev)
+        pag, pkg = torch.empty(GB, P, 16, device=dev), torch.empty(GB, ops.mlp_pack_bytes(), dtype=torch.uint8, device=dev)
+        coordg = dg["image_coord"].reshape(GB, 3, n).contiguous()
+
+        def whole():
+            return ops.RenderStep(dg["pose_to_camera"], dg["bone_length"], cbl_d, dg["z_rend"], mlp, scg["parents"], args.origin, 3.0,
+                                  coordg, dg["inv_intrinsics"], cpose_d, trig, fg, Nc, Nf, parts_out=pag, pack_out=pkg,
+                                  relayout=not args.cache_triplane, seed=99, mlp_mode=args.mlp_mode, want_fine=True,
+                                  early_stop_eps=args.early_stop_eps, march=args.march, group_frames=args.group_frames).run()
+        k1 = max(2, min(args.steps, 8))
+        for _ in range(2):
+            whole()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(k1):
+            whole()
+        torch.cuda.synchronize()
+        dt1 = time.perf_counter() - t1
+        one_gpu_same_job = {"value": GB * n * k1 / dt1, "unit": "rays/s", "ms_per_step": dt1 / k1 * 1e3, "steps": k1,
+                            "frames": GB, "where": "rank 0 of this run, alone, after the timed steps (other ranks at the barrier)",
+                            "note": "same frames and tri-planes as the N-rank job; near / far planes reduced over all frames "
+                                    "here, per rank share there (as DistributedDataParallel does to the reference)"}
+        del trig, fg, pag, pkg, dg
     if rank == 0:
         rays_per_step = B * n_frame if shard else world * B * n
         value = rays_per_step * args.steps / elapsed
@@ -523,6 +588,9 @@ def main():
         }
         if backward is not None:
             out["backward"] = backward
+        if one_gpu_same_job is not None:
+            out["one_gpu_same_job"] = one_gpu_same_job
+            out["speedup_vs_one_gpu_same_job"] = value / one_gpu_same_job["value"]
         if f32_mode is not None:
             out["f32_mode"] = f32_mode
         if two_streams is not None:

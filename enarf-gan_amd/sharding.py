@@ -97,3 +97,83 @@ def all_reduce_gradients(params, world_size: int = None, group=None, bucket_byte
         size += nbytes
     flush()
     return n_coll
+
+
+class GradientReducer:
+    """Bucketed, ASYNCHRONOUS data-parallel gradient exchange with accumulation over micro-batches - what the reference's
+    DistributedDataParallel wrapping does for `n_accum_step` backward passes per optimiser step (train_ENARF_GAN.py:113-126,
+    :203-206: every loss_gen.backward() all-reduces, .grad accumulates).
+
+    `launch(grads)` is called once per micro-batch, as soon as that micro-batch's backward kernels have been enqueued: the
+    gradients are flattened into buckets of ~`bucket_bytes` on the current stream and one all-reduce per bucket is started
+    with async_op=True - on RCCL ("nccl") it runs on the communicator's own stream behind the current stream's work, so the
+    NEXT micro-batch's forward and backward run on the compute stream while the buckets travel over xGMI. `finish()` makes
+    the current stream wait for every bucket and leaves, in `p.grad`, the sum over micro-batches of the rank-averaged
+    gradients. xGMI is point-to-point (7 links x ~153 GB/s per GPU): few large buckets, not one message per tensor."""
+
+    def __init__(self, params, world_size: int = None, group=None, bucket_bytes: int = 64 << 20, average: bool = True):
+        import torch.distributed as dist
+        self.dist, self.group, self.average = dist, group, average
+        self.world = dist.get_world_size(group) if world_size is None else world_size
+        self.params = list(params)
+        self.buckets, cur, size = [], [], 0
+        for i, p in enumerate(self.params):
+            nbytes = p.numel() * p.element_size()
+            if cur and (size + nbytes > bucket_bytes or self.params[cur[0]].dtype != p.dtype):
+                self.buckets.append(cur)
+                cur, size = [], 0
+            cur.append(i)
+            size += nbytes
+        if cur:
+            self.buckets.append(cur)
+        self.pending = []          # (work handle, flat tensor, parameter indices) of every bucket in flight
+        self.collectives = 0
+
+    def launch(self, grads) -> None:
+        """grads: one tensor (or None = zeros) per parameter, this micro-batch's local gradients."""
+        if len(grads) != len(self.params):
+            raise ValueError(f"{len(grads)} gradients for {len(self.params)} parameters")
+        for idx in self.buckets:
+            flat = torch.cat([(grads[i] if grads[i] is not None else torch.zeros_like(self.params[i])).reshape(-1) for i in idx])
+            work = self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self.pending.append((work, flat, idx))
+            self.collectives += 1
+
+    def finish(self) -> int:
+        """Wait for every bucket; p.grad = sum over the launched micro-batches of the (averaged) reduced gradients.
+        Returns the number of collectives since the last finish()."""
+        first = set()
+        for work, flat, idx in self.pending:
+            work.wait()
+            if self.average:
+                flat /= self.world
+            o = 0
+            for i in idx:
+                p = self.params[i]
+                g = flat[o:o + p.numel()].view_as(p)
+                if i in first:
+                    p.grad += g
+                else:
+                    p.grad = g.clone()
+                    first.add(i)
+                o += p.numel()
+        n, self.pending, self.collectives = self.collectives, [], 0
+        return n
+
+
+def accumulate_and_reduce(micro_batches, backward_fn, params, reducer: "GradientReducer" = None) -> None:
+    """One optimiser step's gradient work: for every micro-batch run `backward_fn(mb)` -> list of local gradients (one per
+    parameter) and, with a reducer, start its exchange at once so that it overlaps the next micro-batch; without one
+    (a single process) accumulate locally. Afterwards p.grad holds the step's gradient (bench.py --train-step)."""
+    params = list(params)
+    if reducer is None:
+        for k, mb in enumerate(micro_batches):
+            grads = backward_fn(mb)
+            for p, g in zip(params, grads):
+                if g is None:
+                    g = torch.zeros_like(p)
+                p.grad = g.clone() if k == 0 else p.grad + g
+        return
+    for mb in micro_batches:
+        reducer.launch(backward_fn(mb))
+    reducer.finish()

@@ -89,3 +89,47 @@ def test_two_rank_bucketed_gradient_all_reduce():
     port = 31500 + (os.getpid() % 2000)
     mp.spawn(_grad_worker, args=(2, port, ret), nprocs=2, join=True)
     assert ret["ok"], dict(ret)
+
+
+def _accum_worker(rank, world, port, ret):
+    """Two accumulation steps per rank through sharding.accumulate_and_reduce (the closure bench.py --train-step runs):
+    asynchronous bucketed all-reduce per micro-batch, against the single-process sum over all four micro-batches."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from enarf_gan_amd import sharding
+    g = torch.Generator().manual_seed(7)
+    data = torch.randn(world * 2, 6, 5, generator=g)                # micro-batch k of the job: data[k]
+    w0 = torch.randn(5, 3, generator=g)
+    ps = [torch.nn.Parameter(w0.clone()), torch.nn.Parameter(torch.zeros(3)), torch.nn.Parameter(torch.ones(2, 2))]
+
+    def local_grads(x):                                             # a toy "renderer": the third parameter gets no gradient
+        loss = ((x @ ps[0] + ps[1]).tanh() ** 2).sum()
+        g0, g1 = torch.autograd.grad(loss, ps[:2])
+        return [g0, g1, None]
+
+    red = sharding.GradientReducer(ps, world, bucket_bytes=64)      # 60 B | 12 B + 16 B -> two buckets per micro-batch
+    mine = [data[2 * rank], data[2 * rank + 1]]
+    sharding.accumulate_and_reduce(mine, local_grads, ps, red)
+    n_coll = red.collectives
+    # single process: the average over ranks of every micro-batch, summed over the accumulation steps
+    want0 = sum(local_grads(data[k])[0] for k in range(2 * world)) / world
+    want1 = sum(local_grads(data[k])[1] for k in range(2 * world)) / world
+    ok = torch.allclose(ps[0].grad, want0, atol=1e-6) and torch.allclose(ps[1].grad, want1, atol=1e-6) \
+        and torch.equal(ps[2].grad, torch.zeros(2, 2)) and n_coll == 0 and not red.pending
+    # the same closure without a reducer (one process): plain accumulation
+    qs = [torch.nn.Parameter(w0.clone()), torch.nn.Parameter(torch.zeros(3)), torch.nn.Parameter(torch.ones(2, 2))]
+    sharding.accumulate_and_reduce(mine, local_grads, qs, None)
+    ok = ok and torch.allclose(qs[0].grad, local_grads(mine[0])[0] + local_grads(mine[1])[0], atol=1e-6)
+    if rank == 0:
+        ret["ok"] = bool(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_accumulated_async_gradient_exchange():
+    mgr = mp.get_context("spawn").Manager()
+    ret = mgr.dict()
+    port = 33500 + (os.getpid() % 2000)
+    mp.spawn(_accum_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert ret["ok"], dict(ret)
