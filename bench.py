@@ -29,12 +29,16 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-# MI355X_MICROARCH.md: HBM3E 8 TB/s spec; L2 ~34.5 TB/s aggregate; vector L1 / texture path 64 B/clk/CU; 256 CUs
+# MI355X_MICROARCH.md: HBM3E 8 TB/s spec; L2 ~34.5 TB/s aggregate; 256 CUs
 HBM_PEAK_GBS = 8000.0
 L2_PEAK_GBS = 34500.0
 NUM_CUS = 256
-L1_BYTES_PER_CLK_PER_CU = 64.0
-UB_TA_SHAPE_GBS = 32060.0     # tools/ub_ta.hip, pattern 1, all quads active (profiles/r02_ub_ta.txt)
+# what the CUs' vector-memory (texture) path sustains for the march's access shape - quads reading 2x2 footprints of 128-B
+# texels, 12 waves per CU - MEASURED by tools/ub_ta.hip on this GPU model (pattern 1, all quads active): 32.06 TB/s in
+# round 2 (profiles/r02_ub_ta.txt), 32.50 TB/s in round 3 (profiles/r03_ub_ta.txt); the lower one is the ceiling used
+UB_TA_SHAPE_GBS = 32060.0
+# an ASSUMPTION, not a figure of MI355X_MICROARCH.md: 64 B per clock per CU for the vector L1 (256 CUs x 64 B x 2.4 GHz)
+L1_BYTES_PER_CLK_PER_CU_ASSUMED = 64.0
 BF16_DENSE_TFLOPS = 2500.0
 C3_GLOBAL_FRAMES = 64
 
@@ -79,7 +83,10 @@ def parse():
                     help="device spin-up during set-up, before the W warm-up steps (not part of W or K)")
     ap.add_argument("--no-p24", action="store_true", help="skip the extra timed pass with origin_location center+head (P = 24)")
     ap.add_argument("--no-f32", action="store_true", help="skip the extra timed pass with the exact fp32 MLP arithmetic")
-    ap.add_argument("--no-two-streams", action="store_true", help="skip the extra timed pass over two HIP streams")
+    ap.add_argument("--two-streams", action="store_true",
+                    help="add a timed pass over two HIP streams (off by default: +2 % at 300 steps on the build boxes, -3 % in the "
+                         "driver's 20-step run of round 2 - within the noise of a 5 ms timed region)")
+    ap.add_argument("--no-two-streams", action="store_true", help="accepted and ignored (the pass is opt-in since round 3)")
     ap.add_argument("--allow-variant", action="store_true", help="measurement only: permit --variant")
     ap.add_argument("--variant", default=None, help="another build of the same ABI (tools/build_variant.sh); needs --allow-variant")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -114,10 +121,10 @@ def cpu_baseline(scene_cpu, Nc, Nf, n_rays, budget_s):
 
 
 def counter_fractions(workload_key, kernel_ms):
-    """Counter-backed utilisation of the march from the committed rocprofv3 summary (profiles/r02_roofline.json, written
+    """Counter-backed utilisation of the march from the committed rocprofv3 summary (profiles/r03_roofline.json, written
     by tools/pmc_summary.py from separate --pmc passes of this very command). Attached only when the profiled workload is
     the one being run; every entry names its counters and its source file."""
-    path = os.path.join(ROOT, "profiles", "r02_roofline.json")
+    path = os.path.join(ROOT, "profiles", "r03_roofline.json")
     if not os.path.exists(path):
         return None
     try:
@@ -433,7 +440,7 @@ def main():
         f32_mode = {"workload": "the same step with the exact fp32 MLP arithmetic (v_mfma_f32_16x16x4_f32)",
                     "value": B * n * args.steps / dt, "unit": "rays/s", "ms_per_step": dt / args.steps * 1e3}
     two_streams = None
-    if extras and n_streams == 1 and not args.no_two_streams:
+    if extras and n_streams == 1 and args.two_streams:
         # the same K steps alternating over two HIP streams with private intermediates: the next step's pre-march launch
         # (serial chains of a few blocks) runs in the tail of the persistent march. Reported beside `value`, which stays
         # the single-stream number the roofline figures are measured on.
@@ -519,7 +526,7 @@ def main():
         t_k = kern_ms * 1e-3
         q = rays_marched * (Nc + Nf - 1)
         clock_ghz = 2.4
-        l1_peak = NUM_CUS * L1_BYTES_PER_CLK_PER_CU * clock_ghz          # GB/s: what the CUs' texture paths can deliver
+        l1_assumed = NUM_CUS * L1_BYTES_PER_CLK_PER_CU_ASSUMED * clock_ghz          # GB/s, an assumption (see above)
         workload_key = f"C1:{S}:{B}:{Nc}:{Nf}:{P}:{args.mlp_mode}:{int(distinct)}:{args.early_stop_eps}"
         if args.march != "auto":
             workload_key += f":{args.march}"
@@ -534,13 +541,13 @@ def main():
             # the texel gathers are L1/L2 hits (the tri-plane is read from HBM once): the roofline that bounds the march is
             # the CUs' vector-memory (texture) path, not HBM. `achieved` = algorithmic texel bytes / kernel time.
             "bound": "l1-texture-path", "kernel": kernel_name,
-            "achieved": gather_bytes / t_k / 1e9, "peak": l1_peak, "unit": "GB/s", "frac": gather_bytes / t_k / 1e9 / l1_peak,
-            "peak_note": f"{NUM_CUS} CUs x {L1_BYTES_PER_CLK_PER_CU:.0f} B/clk x {clock_ghz} GHz (MI355X_MICROARCH.md: 16-B-per-lane loads "
-                         "take 16 clk per wave instruction)",
-            # what the same path sustains for exactly this access shape (2x2 footprints of 128-B texels read by quads, 12
-            # waves per CU), measured by tools/ub_ta.hip on this GPU model: profiles/r02_ub_ta.txt, pattern 1, 16/16 quads
-            "shape_ceiling": {"value": UB_TA_SHAPE_GBS, "unit": "GB/s", "frac": gather_bytes / t_k / 1e9 / UB_TA_SHAPE_GBS,
-                              "source": "profiles/r02_ub_ta.txt"},
+            "achieved": gather_bytes / t_k / 1e9, "peak": UB_TA_SHAPE_GBS, "unit": "GB/s", "frac": gather_bytes / t_k / 1e9 / UB_TA_SHAPE_GBS,
+            "peak_note": "MEASURED ceiling of the CUs' texture path for this access shape (2x2 footprints of 128-B texels read by "
+                         "quads, 12 waves per CU): tools/ub_ta.hip pattern 1, 16/16 quads, profiles/r02_ub_ta.txt (32.06 TB/s; "
+                         "32.50 TB/s in profiles/r03_ub_ta.txt). MI355X_MICROARCH.md gives no L1 bandwidth figure",
+            # for comparison with rounds 1-2, which divided by an ASSUMED 64 B per clock per CU (not a figure of the guide)
+            "assumed_64B_per_clk_per_cu": {"value": l1_assumed, "unit": "GB/s", "frac": gather_bytes / t_k / 1e9 / l1_assumed,
+                                           "note": f"{NUM_CUS} CUs x 64 B/clk x {clock_ghz} GHz: an assumption, kept so that rounds can be compared"},
             "kernel_ms": kern_ms, "gather_bytes_per_launch": gather_bytes, "compulsory_hbm_bytes_per_launch": compulsory,
             "hbm_frac_if_every_gather_missed": (gather_bytes + compulsory) / t_k / 1e9 / HBM_PEAK_GBS,
             "compulsory_hbm_frac": compulsory / t_k / 1e9 / HBM_PEAK_GBS,

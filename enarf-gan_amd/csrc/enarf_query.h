@@ -217,7 +217,12 @@ __device__ __forceinline__ f32x4 act4(f32x4 v) {
 
 // ---- fp32 MFMA blocks (v_mfma_f32_16x16x4_f32), accumulate in place -------------------------------------------------------
 // Same rule as the split-precision MLP below (see there): every chained MFMA is issued from an asm block with tied
-// accumulators, independent chains interleaved, a trailing s_nop for the last write -> VALU read distance (8 passes + 3).
+// accumulators, independent chains interleaved, and the wait states the compiler cannot add inside an asm string:
+//   * leading  `s_nop 1`       a just-written "v" operand -> MFMA operand needs 2 states;
+//   * trailing `s_nop 7; s_nop 4` = 13 states: an MFMA's D -> any reader or writer other than the next MFMA taking it whole as C
+//     needs passes + 4 = 12 states for this 8-pass instruction (32 clk per instruction per SIMD; cdna_hip_programming.md 5.7
+//     item 2: "8-pass XDL: 12 states"), and the block's last MFMA is followed by compiler code that reads the accumulators.
+// tools/check_mfma_chains.py measures both distances in the built library (part of the CPU test suite and of build()).
 // Summation order per output element = ascending k, as before: the results are bitwise those of an fmaf chain.
 #define ENARF_M32(d, a, b) "v_mfma_f32_16x16x4_f32 %" #d ", %" #a ", %" #b ", %" #d "\n\t"
 #define ENARF_M32_TAIL "s_nop 7\n\ts_nop 4"
@@ -420,8 +425,10 @@ __device__ __forceinline__ void split8h(const float v[8], i32x4 &hi, i32x4 &lo) 
 }
 
 // c_i += A_i . B for four independent 16x16 output blocks (A_i: weights of block i as [hi, lo][64 lanes][8] in LDS, `stride`
-// shorts apart; B: the split activations). Term order per chain: hi*hi, hi*lo(B), lo(A)*hi. The trailing s_nop covers
-// the matrix-pipe write -> VALU read distance of the last MFMA (the compiler cannot see into the block).
+// shorts apart; B: the split activations). Term order per chain: hi*hi, hi*lo(B), lo(A)*hi. The trailing `s_nop 7; s_nop 1`
+// = 10 states covers the D -> reader distance of the last MFMA (the compiler cannot see into the block):
+// v_mfma_f32_16x16x32_{f16,bf16} is a 4-pass instruction on gfx950 (16 clk per instruction per SIMD, MI355X_MICROARCH.md
+// cycle table), passes + 4 = 8 states (cdna_hip_programming.md 5.7 item 2); checked by tools/check_mfma_chains.py.
 #define ENARF_MFMA4X3(OP)                                                                                                    \
     asm volatile("s_nop 1\n\t"                                                                                              \
                  OP " %0, %4, %12, %0\n\t" OP " %1, %5, %12, %1\n\t" OP " %2, %6, %12, %2\n\t" OP " %3, %7, %12, %3\n\t"          \

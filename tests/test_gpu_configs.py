@@ -307,3 +307,35 @@ def test_grouped_batch_gives_the_same_bits_as_one_launch():
     assert_close(outs[1][0].cpu(), outs[0][0].cpu(), "grad_tri, grouped backward", 2e-5)
     for l in range(3):
         assert_close(outs[1][1][l].cpu(), outs[0][1][l].cpu(), f"dW{l}, grouped backward", 2e-5)
+
+
+def test_first_launch_of_a_fresh_process_equals_the_second():
+    """Regression test of commit 62f9e8b (render_kernel lost its barrier after staging the FIRST image context when the bin
+    table moved up: the first rays of a launch could run on a half-staged MLP pack - visible only on the first launch of a
+    process, with cold instruction caches and LDS, and not in a long-lived pytest process). A fresh interpreter renders the
+    same frames twice with both march kernels, first launch on a fresh workspace included; every launch must give the same bits."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import hashlib, sys, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from _helpers import DeviceScene, Scene
+sc = Scene(64, 2, "center_fixed", 20)
+ds = DeviceScene(sc)
+for march in ("ray", "task"):
+    sigs = []
+    for rep in range(3):
+        o = ds.render(sc.raw["image_coord"], 48, 32, None, seed=4, mlp_mode="f16x3", march=march, count=True, return_bins=True)
+        torch.cuda.synchronize()
+        h = hashlib.md5(b"".join(t.cpu().numpy().tobytes() for t in (o.color, o.mask, o.disparity, o.fine_depth, o.taps["bins"]))).hexdigest()
+        sigs.append((h, tuple(o.counters.cpu().tolist())))
+    print("SIG", march, len(set(sigs)), sigs[0][0], sigs[0][1][7])
+''' % (root, os.path.join(root, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    lines = [l.split() for l in r.stdout.splitlines() if l.startswith("SIG")]
+    assert len(lines) == 2, r.stdout + r.stderr
+    for _, march, distinct, h, watchdog in lines:
+        assert distinct == "1" and watchdog == "0", (march, r.stdout)
+    assert lines[0][3] == lines[1][3], "the two march kernels disagree on a first launch"

@@ -252,6 +252,39 @@ def test_query_ragged_and_empty(ops):
     assert den.shape == (1, 1, 0)
 
 
+def test_query_culling_does_not_depend_on_stale_lds(ops, tmp_path):
+    """Regression test of ADVICE r02 (high): query_kernel computed the per-part cull radii from part frames in LDS right
+    after stage_common(), which ends without a barrier - wave 0 could read frames waves 1-3 had not written yet and cull a
+    part with a garbage radius. It passed as long as the LDS still held the same frames from an earlier workgroup. Here
+    every CU's LDS is overwritten with NaN / huge bit patterns (tests/host/lds_poison.hip, built with hipcc) before each
+    launch of enarf_query_fwd at B = 3 (other frames per image), and the culled production path must equal the debug path
+    (which keeps every part as a candidate) bit for bit, launch after launch."""
+    import ctypes as C
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = str(tmp_path / "liblds_poison.so")
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-shared", "-fPIC",
+                    os.path.join(root, "tests", "host", "lds_poison.hip"), "-o", so], check=True, capture_output=True)
+    lib = C.CDLL(so)
+    lib.lds_poison.restype, lib.lds_poison.argtypes = C.c_int, [C.c_uint, C.c_void_p]
+    sc = Scene(32, 3, "center+head", 20)
+    ds = DeviceScene(sc)
+    g = torch.Generator().manual_seed(4)
+    jp = sc.pose_scaled[:, :, :3, 3]
+    pick = torch.randint(0, jp.shape[1], (3, 20000), generator=g)
+    pts = (torch.gather(jp, 1, pick[..., None].expand(-1, -1, 3)).permute(0, 2, 1) + 0.4 * torch.randn(3, 3, 20000, generator=g)).contiguous()
+    ref = ds.query(pts, mlp_mode="f32", debug=True)            # density, colour, valid bits (+ taps): no culling
+    assert int((ref[2] != 0).sum()) > 10000
+    stream = torch.cuda.current_stream().cuda_stream
+    for pattern in (0x7FC00000, 0x7F7FFFFF, 0xFFFFFFFF, 0x00000000):     # NaN, FLT_MAX, -NaN, zeros
+        for _ in range(3):
+            assert lib.lds_poison(pattern, stream) == 0
+            den, col, vb = ds.query(pts, mlp_mode="f32", need_valid=True)
+            assert torch.equal(vb, ref[2]), hex(pattern)
+            assert torch.equal(den, ref[0]) and torch.equal(col, ref[1]), hex(pattern)
+
+
 def test_query_multiply_density_with_weight(ops):
     sc = Scene(32, 1, "center_fixed", 20)
     ds = DeviceScene(sc)

@@ -312,3 +312,88 @@ def test_unsupported_configs_raise():
     m = TriPlaneNARF(_nerf_cfg(constant_triplane=False), 20, 24, parent=synth.SMPL_PARENTS)
     with pytest.raises(NotImplementedError):
         m.compute_tri_plane_feature(torch.zeros(1, 20), torch.ones(1, 23, 1))
+
+
+# ---------------------------------------------------------------------------------------------- on-disk formats
+def _dso_generator():
+    from enarf_gan_amd import synth
+    from enarf_gan_amd.models.generator import DSONARFGenerator
+    g = DSONARFGenerator(Cfg(use_triplane=True, ray_batchsize=4096, nerf_params=_nerf_cfg()), 128, 24, synth.SMPL_PARENTS, 23)
+    g.register_canonical_pose(synth.canonical_pose())
+    return g
+
+
+def test_reference_snapshot_schema_loads_into_the_mirror_generator(tmp_path):
+    """A snapshot in the reference's schema (train_ENARF_GAN.py:278-294) - written here with synthetic weights, under
+    DistributedDataParallel's "module." prefix, with keys of networks this repo does not build - loads by name into the
+    mirror generator (DSO_demo.py:37-42: strict=False); what was not loaded is reported; round trip through save_snapshot."""
+    from enarf_gan_amd import formats
+    src = _dso_generator()
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        for p in src.parameters():
+            p.copy_(torch.randn(p.shape, generator=g))
+    gen_sd = {"module." + k: v.clone() for k, v in src.state_dict().items()}
+    gen_sd["module.background_generator.conv1.weight"] = torch.randn(4, 4)          # un-vendored StyleGAN2 parts
+    gen_sd["module.nerf.mlp.layers.0.conv.weight"] = gen_sd["module.nerf.mlp.layers.0.conv.weight"].clone()
+    path = tmp_path / "snapshot_latest.pth"
+    torch.save({"iteration": 1199, "start_time": 0.0, "gen": gen_sd, "dis": {"convs.0.weight": torch.zeros(2)},
+                "gen_opt": {"state": {}, "param_groups": []}, "dis_opt": {}}, path)
+    dst = _dso_generator()
+    rep = formats.load_generator_snapshot(path, dst)
+    assert rep.iteration == 1199 and rep.ignored == ["background_generator.conv1.weight"] and not rep.missing
+    for k, v in src.state_dict().items():
+        assert torch.equal(dst.state_dict()[k], v), k
+    # a snapshot with another style width: the modulation weights do not fit and are reported, strict=True refuses
+    bad = {k: v for k, v in src.state_dict().items()}
+    bad["nerf.mlp.layers.1.conv.modulation.weight"] = torch.zeros(64, 256)
+    rep = formats.load_generator_snapshot({"gen": bad, "iteration": 3}, _dso_generator())
+    assert rep.missing == ["nerf.mlp.layers.1.conv.modulation.weight"] and rep.ignored == ["nerf.mlp.layers.1.conv.modulation.weight"]
+    with pytest.raises(RuntimeError):
+        formats.load_generator_snapshot({"gen": bad}, _dso_generator(), strict=True)
+    # our own snapshot in the same schema
+    out = tmp_path / "snapshot_50000.pth"
+    formats.save_snapshot(out, dst, 49999)
+    snap = formats.read_snapshot(out)
+    assert set(snap) == {"iteration", "start_time", "gen", "dis", "gen_opt", "dis_opt"} and snap["iteration"] == 49999
+    assert torch.equal(snap["gen"]["nerf.tri_plane"], src.state_dict()["nerf.tri_plane"])
+
+
+def test_cache_and_sample_data_readers(tmp_path):
+    """cache.pickle (dataset/dataset.py:152-185) and sample_data.pickle (prepare_sample_data.py:59-66) written here with the
+    reference's keys and shapes; the readers rebuild numpy arrays only and refuse a pickle that names any other global."""
+    import pickle
+    from enarf_gan_amd import formats, synth
+    rs = np.random.RandomState(0)
+    N = 5
+    pose = synth.make_scene(32, N)["pose_to_camera"].numpy().astype(np.float64)
+    K = np.broadcast_to(np.array([[150.0, 0, 64], [0, 150.0, 64], [0, 0, 1]]), (N, 3, 3)).copy()
+    R = np.stack([np.linalg.qr(rs.randn(3, 3))[0] for _ in range(N)])
+    T = rs.randn(N, 3, 1)
+    cache = {"img": [bytes([i]) * 10 for i in range(N)], "camera_intrinsic": K, "smpl_pose": pose, "camera_rotation": R,
+             "camera_translation": T, "frame_id": np.arange(N)}
+    p = tmp_path / "cache.pickle"
+    pickle.dump(cache, open(p, "wb"))
+    c = formats.read_cache(p)
+    ext = np.broadcast_to(np.eye(4), (N, 4, 4)).copy()
+    ext[:, :3, :3], ext[:, :3, 3:] = R, T
+    assert np.array_equal(c.pose_to_camera, np.matmul(ext[:, None], pose)) and np.array_equal(c.pose_to_world, pose)
+    assert np.allclose(c.inv_intrinsics @ K, np.eye(3)) and len(c.img) == N and np.array_equal(c.frame_id, np.arange(N))
+    with pytest.raises(ImportError):
+        formats.unpack_image(c.img[0])                 # blosc is the reference's dependency, not installed here
+    del cache["camera_rotation"], cache["camera_translation"]
+    pickle.dump(cache, open(p, "wb"))
+    assert np.array_equal(formats.read_cache(p).pose_to_camera, pose)
+    rows = [{"pose_3d": pose[i], "intrinsics": K[i].astype(np.float32), "bone_length": rs.rand(23, 1)} for i in range(3)]
+    q = tmp_path / "sample_data.pickle"
+    pickle.dump(rows, open(q, "wb"))
+    sd = formats.read_sample_data(q)
+    assert sd.pose_3d.shape == (3, 24, 4, 4) and sd.intrinsics.dtype == np.float32 and sd.bone_length.shape == (3, 23, 1)
+    # a pickle that would run code is refused before anything is called
+    class Evil:
+        def __reduce__(self):
+            import os
+            return (os.system, ("echo pwned > /dev/null",))
+    pickle.dump({"img": [], "camera_intrinsic": Evil()}, open(p, "wb"))
+    with pytest.raises(formats.UnsafePickleError):
+        formats.read_cache(p)

@@ -7,7 +7,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
 sub = sys.argv[2] if len(sys.argv) > 2 else "pmc_final"
 src = os.path.join(root, "gpurun_out", sub)
-default_workload = sub == "pmc_final"           # only the default C1 profile feeds bench.py (traffic.json, r02_roofline.json)
+default_workload = sub == "pmc_final"           # only the default C1 profile feeds bench.py (traffic.json, r03_roofline.json)
 names = {"enarf::march_kernel<": "march", "enarf::render_kernel<": "march", "enarf::pre_march_kernel": "pre", "ray_setup_kernel": "setup"}
 lines = ["# rocprofv3 --pmc (one group per run, with --kernel-trace only) on: python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-p24 --spinup-ms 0",
          "# workload C1: 128x128 rays, B=1, Nc 48 + Nf 64, P=23, f16x3; mean over the launches of each kernel",
@@ -69,5 +69,5 @@ if st and ("march", "SQ_WAVE_CYCLES") in vals:
     json.dump({"workload_key": os.environ.get("WORKLOAD_KEY", "C1:128:1:48:64:23:f16x3:0:0.0"), "kernel_ms": t_ns * 1e-6, "cycles_per_launch": cycles,
                "clock_ghz_under_profiler": cycles / t / 1e9, "hbm_bytes_per_launch": int(hbm_bytes), "limiter": limiter, "fractions": fr,
                "kernel_stats": f"profiles/{tag}_kernel_stats.csv"},
-              open(os.path.join(root, "profiles", "r02_roofline.json" if default_workload else f"{tag}_roofline.json"), "w"), indent=1)
+              open(os.path.join(root, "profiles", "r03_roofline.json" if default_workload else f"{tag}_roofline.json"), "w"), indent=1)
 print("\n".join(lines[4:]))
