@@ -333,7 +333,9 @@ __device__ __forceinline__ f32x4 mlp_tile_f32(const float *__restrict__ Wp, cons
 __device__ __forceinline__ float styled_act_grad(float a) { return (a > 0.0f ? 1.0f : 0.2f) * 1.41421356237309515f; }
 
 // backward: dz3v = dL/dz3[unit g][point j] of this lane (lane = 16g + j); returns dz2, dz1 (accumulator layout) and
-// dx[8] = dL/d feature channels 8g..8g+7 of point j.  Wt = transposed section of the pack (LDS).
+// dx[8] = dL/d feature channels 8g..8g+7 of point j (WANT_DX = false: not computed - the weight-gradient kernel needs only
+// dz2 and dz1 and saves the last product's 32 MFMAs).  Wt = transposed section of the pack (LDS).
+template <bool WANT_DX = true>
 __device__ __forceinline__ void mlp_bwd_tile_f32(const float *__restrict__ Wt, const f32x4 a1[4], const f32x4 a2[4],
                                                  float dz3v, int lane, f32x4 dz2[4], f32x4 dz1[4], float dx[8]) {
     const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -365,6 +367,11 @@ __device__ __forceinline__ void mlp_bwd_tile_f32(const float *__restrict__ Wt, c
     for (int ob = 0; ob < 4; ++ob)
 #pragma unroll
         for (int r = 0; r < 4; ++r) dz1[ob][r] *= styled_act_grad(a1[ob][r]);
+    if constexpr (!WANT_DX) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) dx[r] = 0.0f;
+        return;
+    }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         float a[2][8], b[8];

@@ -128,6 +128,39 @@ __device__ __forceinline__ void mask_tap_add(float *__restrict__ gmask, bool on,
     if (on && tail) { atomicAdd(gmask + elem, acc); n_adds += 1; }
 }
 
+// A/B (ENARF_BWD_MASK_ROWMAJOR=1): the same adds with the wave re-laid as lane = 32 row + 2 sample + x-tap, so that all
+// taps of one texel row sit in consecutive lanes (one permute each for the element and the value), runs of equal elements
+// merged along the samples (lanes 2 apart, rows of 8 samples) - does the memory side then see one request per touched
+// 64-byte segment instead of one per sample and row?
+#ifndef ENARF_BWD_F4_ROUNDS            // A/B: rounds of the scatter pass whose loads are all issued before any of their atomics.
+#define ENARF_BWD_F4_ROUNDS 1          // 1 = loads and adds alternate round by round. Measured at C1: 1 -> 1.628 ms, 4 -> 1.660, 8 -> 1.653
+#endif
+#ifndef ENARF_BWD_MASK_ROWMAJOR
+#define ENARF_BWD_MASK_ROWMAJOR 0
+#endif
+__device__ __forceinline__ void mask_tap_add_rowmajor(float *__restrict__ gmask, bool on, int elem, float v, int lane, unsigned &n_adds) {
+    // source lane (sample q, tap t = 2 row + x) = 4 q + t  ->  lane 32 row + 2 q + x
+    const int src = 4 * ((lane >> 1) & 15) + 2 * (lane >> 5) + (lane & 1);
+    const int key_own = on ? elem : -2 - lane;
+    const int key = __builtin_amdgcn_ds_bpermute(src << 2, key_own);
+    float acc = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src << 2, __builtin_bit_cast(int, on ? v : 0.0f)));
+    const bool live = key >= 0;
+    auto shr = [](int old, int x, int sel) {
+        return sel == 0 ? __builtin_amdgcn_update_dpp(old, x, 0x112, 0xF, 0xF, false)       // row_shr:2
+             : sel == 1 ? __builtin_amdgcn_update_dpp(old, x, 0x114, 0xF, 0xF, false)       // row_shr:4
+                        : __builtin_amdgcn_update_dpp(old, x, 0x118, 0xF, 0xF, false);      // row_shr:8
+    };
+    int head = (shr(-1, key, 0) != key) ? 1 : 0;
+#pragma unroll
+    for (int sel = 0; sel < 3; ++sel) {
+        const float pv = __builtin_bit_cast(float, shr(0, __builtin_bit_cast(int, acc), sel));
+        const int ph = shr(1, head, sel);
+        if (!head) { acc += pv; head |= ph; }
+    }
+    const bool tail = __builtin_amdgcn_update_dpp(-1, key, 0x102, 0xF, 0xF, false) != key;      // row_shl:2: the next sample starts another run
+    if (live && tail) { atomicAdd(gmask + key, acc); n_adds += 1; }
+}
+
 // what the per-tile stages of the backward need besides the query context (shared by the ray and the point kernels)
 struct BwdTile {
     int H, W;
@@ -238,76 +271,112 @@ __device__ __forceinline__ void bwd_backward_tile(const QueryCtx &S, const BwdTi
 #pragma unroll
     for (int c = 0; c < 8; ++c) dxg[c] = __shfl(dxm[c], src2);
 
-    // ---- F4: second pass over the pairs: d part-probability and d feature texels
-    uint32_t rem = (ENARF_BWD_ABLATE & 4) ? 0u : bits;
-    __builtin_amdgcn_s_setprio(2);          // memory rounds ahead of the other waves' MFMA phases (as in the forward)
-    while (true) {
-        const uint64_t bal = __ballot(rem != 0);
-        if (bal == 0) { __builtin_amdgcn_s_setprio(0); break; }
-        C.pairs += (unsigned)(__popcll(bal) >> 2);
-        C.rounds += 1;
-        const bool act = rem != 0;
-        const int k = act ? __builtin_ctz(rem) : 0;
-        rem &= rem - 1;
+    // ---- F4: second pass over the pairs: d part-probability and d feature texels.
+    // In chunks of kF4Rounds rounds, each chunk in TWO sub-passes: (a) everything that LOADS - the part-probability taps and
+    // the 12 feature texels of every pair, for dL/d part weight - then (b) everything that ADDS; (b) recomputes a round's taps
+    // from the frames in LDS (VALU only) and keeps two floats per round from (a). The idea behind chunks > 1: on gfx9 loads
+    // and no-return atomics share vmcnt, so a wait for a load result while atomics are outstanding is s_waitcnt vmcnt(0) and
+    // drains every atomic the wave has in flight; alternating round by round that is one drain per round, in chunks one per
+    // chunk. Measured (profiles/r03_bwd_lds_merge_ab.log): no gain - 1.628 ms (1), 1.660 (4), 1.653 (8) at C1: the waves are
+    // not waiting on those drains. The product keeps chunks of 1.
+    constexpr int kF4Rounds = ENARF_BWD_F4_ROUNDS;
+    auto round_taps = [&](int k) {      // this lane's own-plane taps of part k at the sample (lane 3 repeats plane 0)
         float F[13], Cn[12], lx, ly, lz, cx, cy, cz;
         load_frames(S, k, F, Cn);
         exact_local(F, px, py, pz, lx, ly, lz);
         exact_canonical(Cn, F[12], lx, ly, lz, cx, cy, cz);
         const float qx = (g4 == 1) ? cy : (g4 == 2) ? cz : cx;
         const float qy = (g4 == 1) ? cz : (g4 == 2) ? cx : cy;
-        const Taps t = make_taps(qx, qy, T.H, T.W);
-        float sg = 1.0f;
-        if (act && g4 < 3) {
-            const float *mp = S.mask + (size_t)(3 * k + g4) * T.mplane;
-            float acc = mp[t.o00] * t.w00;
-            acc += mp[t.o01] * t.w01;
-            acc += mp[t.o10] * t.w10;
-            acc += mp[t.o11] * t.w11;
-            if (S.clamp_mask) acc = fminf(fmaxf(acc, -2.0f), 5.0f);     // gradient straight through (sampling.py:46-47)
-            sg = sigmoidf_(acc);
-        }
-        const float wp = (quad_bcast_f<0>(sg) * quad_bcast_f<1>(sg)) * quad_bcast_f<2>(sg);
-        const float wk = (S.uniform_w > 0.0f) ? S.uniform_w : wp;
-        const Taps t0 = quad_bcast_taps<0>(t), t1 = quad_bcast_taps<1>(t), t2 = quad_bcast_taps<2>(t);
-        float dot = 0.0f;
-        if (act) {
-            float s0[8], s1[8], s2[8];
-            const float *featg = S.feat + 8 * g4;
-            tap4(featg, t0, s0);
-            tap4(featg + T.fplane, t1, s1);
-            tap4(featg + 2 * T.fplane, t2, s2);
+        return make_taps(qx, qy, T.H, T.W);
+    };
+    uint32_t rem = (ENARF_BWD_ABLATE & 4) ? 0u : bits;
+    __builtin_amdgcn_s_setprio(2);          // memory rounds ahead of the other waves' MFMA phases (as in the forward)
+    while (__ballot(rem != 0) != 0) {
+        float wk_r[kF4Rounds], gm_r[kF4Rounds];
+        // ---- (a) loads
+        uint32_t rem_a = rem;
 #pragma unroll
-            for (int c = 0; c < 8; ++c) dot += dxg[c] * ((s0[c] + s1[c]) + s2[c]);
-        }
-        dot += quad_perm_f<0xB1>(dot);
-        dot += quad_perm_f<0x4E>(dot);                                  // d loss / d w_k, quad-uniform
-        if (act && k == kmax) dot += gwm;                               // density = MyReLU(.) * 10 * max_k w_k (narf.py:271-272)
-        {   // w = s0 s1 s2, s = sigmoid(m): dw/dm_p = w (1 - s_p) for plane p, spread over the plane's four taps.
-            // One wave-instruction per PLANE with lane = (quad, tap): the two taps of a row are adjacent floats in adjacent
-            // lanes, so they leave as ONE 64-byte request at the memory side, where the atomics are counted and paid for
-            // (round 2 issued one instruction per tap slot with lane = (quad, plane): every add its own request - 8.3 M of
-            // the 20.4 M requests of a C1 backward, profiles/r03_bwd_a_pmc_summary.txt)
-            const bool mon = act && !(ENARF_BWD_ABLATE & 2) && !(S.uniform_w > 0.0f);     // uniform weights: no plane gradient
-            const float gm = dot * wp * (1.0f - sg);                                       // lane g4 < 3: its own plane's
-#define ENARF_MASK_PLANE(PL)                                                                                                   \
-            {   /* all eight broadcasts run with the whole quad enabled (a DPP read of a disabled lane returns nothing) */        \
-                const int o0 = quad_bcast_i<PL>(t.o00), o1 = quad_bcast_i<PL>(t.o01), o2 = quad_bcast_i<PL>(t.o10), o3 = quad_bcast_i<PL>(t.o11); \
-                const float w0 = quad_bcast_f<PL>(t.w00), w1 = quad_bcast_f<PL>(t.w01), w2 = quad_bcast_f<PL>(t.w10), w3 = quad_bcast_f<PL>(t.w11); \
-                const float gp = quad_bcast_f<PL>(gm);                                                                         \
-                const int o = (g4 == 0) ? o0 : (g4 == 1) ? o1 : (g4 == 2) ? o2 : o3;                                           \
-                const float w = (g4 == 0) ? w0 : (g4 == 1) ? w1 : (g4 == 2) ? w2 : w3;                                         \
-                mask_tap_add(T.gmask, mon && w != 0.0f, (3 * k + PL) * (int)T.mplane + o, w * gp, lane, C.mask_adds);          \
+        for (int r = 0; r < kF4Rounds; ++r) {
+            wk_r[r] = 0.0f; gm_r[r] = 0.0f;
+            const uint64_t bal = __ballot(rem_a != 0);
+            if (bal != 0) {
+                C.pairs += (unsigned)(__popcll(bal) >> 2);
+                C.rounds += 1;
+                const bool act = rem_a != 0;
+                const int k = act ? __builtin_ctz(rem_a) : 0;
+                rem_a &= rem_a - 1;
+                const Taps t = round_taps(k);
+                float sg = 1.0f;
+                if (act && g4 < 3) {
+                    const float *mp = S.mask + (size_t)(3 * k + g4) * T.mplane;
+                    float acc = mp[t.o00] * t.w00;
+                    acc += mp[t.o01] * t.w01;
+                    acc += mp[t.o10] * t.w10;
+                    acc += mp[t.o11] * t.w11;
+                    if (S.clamp_mask) acc = fminf(fmaxf(acc, -2.0f), 5.0f);     // gradient straight through (sampling.py:46-47)
+                    sg = sigmoidf_(acc);
+                }
+                const float wp = (quad_bcast_f<0>(sg) * quad_bcast_f<1>(sg)) * quad_bcast_f<2>(sg);
+                const Taps t0 = quad_bcast_taps<0>(t), t1 = quad_bcast_taps<1>(t), t2 = quad_bcast_taps<2>(t);
+                float dot = 0.0f;
+                if (act) {
+                    float s0[8], s1[8], s2[8];
+                    const float *featg = S.feat + 8 * g4;
+                    tap4(featg, t0, s0);
+                    tap4(featg + T.fplane, t1, s1);
+                    tap4(featg + 2 * T.fplane, t2, s2);
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) dot += dxg[c] * ((s0[c] + s1[c]) + s2[c]);
+                }
+                dot += quad_perm_f<0xB1>(dot);
+                dot += quad_perm_f<0x4E>(dot);                                  // d loss / d w_k, quad-uniform
+                if (act && k == kmax) dot += gwm;                               // density = MyReLU(.) * 10 * max_k w_k (narf.py:271-272)
+                wk_r[r] = (S.uniform_w > 0.0f) ? S.uniform_w : wp;
+                // w = s0 s1 s2, s = sigmoid(m): dw/dm_p = w (1 - s_p) for plane p (lane p of the quad)
+                gm_r[r] = dot * wp * (1.0f - sg);
             }
-            ENARF_MASK_PLANE(0)
-            ENARF_MASK_PLANE(1)
-            ENARF_MASK_PLANE(2)
-#undef ENARF_MASK_PLANE
         }
-        // every lane takes part (wave-uniform): inactive quads contribute empty rows
-        scatter_plane(T.gfeat, T.ttile, t0, wk, act, dxg, lane, C.lines);
-        scatter_plane(T.gfeat + T.fplane, T.ttile, t1, wk, act, dxg, lane, C.lines);
-        scatter_plane(T.gfeat + 2 * T.fplane, T.ttile, t2, wk, act, dxg, lane, C.lines);
+        // ---- (b) adds: no load result is needed from here to the end of the chunk
+#pragma unroll
+        for (int r = 0; r < kF4Rounds; ++r) {
+            if (__ballot(rem != 0) != 0) {
+                const bool act = rem != 0;
+                const int k = act ? __builtin_ctz(rem) : 0;
+                rem &= rem - 1;
+                const Taps t = round_taps(k);
+                const float wk = wk_r[r], gm = gm_r[r];
+                {   // One wave-instruction per PLANE with lane = (quad, tap): the two taps of a row are adjacent floats in
+                    // adjacent lanes, so they leave as ONE 64-byte request at the memory side, where the atomics are counted and
+                    // paid for (round 2 issued one instruction per tap slot with lane = (quad, plane): every add its own request -
+                    // 8.3 M of the 20.4 M requests of a C1 backward, profiles/r03_bwd_a_pmc_summary.txt). Uniform weights
+                    // (no_selector): no plane gradient
+                    const bool mon = act && !(ENARF_BWD_ABLATE & 2) && !(S.uniform_w > 0.0f);
+#define ENARF_MASK_PLANE(PL)                                                                                                   \
+                    {   /* all broadcasts run with the whole quad enabled (a DPP read of a disabled lane returns nothing) */      \
+                        const int o0 = quad_bcast_i<PL>(t.o00), o1 = quad_bcast_i<PL>(t.o01), o2 = quad_bcast_i<PL>(t.o10), o3 = quad_bcast_i<PL>(t.o11); \
+                        const float w0 = quad_bcast_f<PL>(t.w00), w1 = quad_bcast_f<PL>(t.w01), w2 = quad_bcast_f<PL>(t.w10), w3 = quad_bcast_f<PL>(t.w11); \
+                        const float gp = quad_bcast_f<PL>(gm);                                                                 \
+                        const int o = (g4 == 0) ? o0 : (g4 == 1) ? o1 : (g4 == 2) ? o2 : o3;                                   \
+                        const float w = (g4 == 0) ? w0 : (g4 == 1) ? w1 : (g4 == 2) ? w2 : w3;                                 \
+                        if (ENARF_BWD_MASK_ROWMAJOR)                                                                           \
+                            mask_tap_add_rowmajor(T.gmask, mon && w != 0.0f, (3 * k + PL) * (int)T.mplane + o, w * gp, lane, C.mask_adds); \
+                        else                                                                                                   \
+                            mask_tap_add(T.gmask, mon && w != 0.0f, (3 * k + PL) * (int)T.mplane + o, w * gp, lane, C.mask_adds); \
+                    }
+                    ENARF_MASK_PLANE(0)
+                    ENARF_MASK_PLANE(1)
+                    ENARF_MASK_PLANE(2)
+#undef ENARF_MASK_PLANE
+                }
+                // every lane takes part (wave-uniform): inactive quads contribute empty rows
+                const Taps t0 = quad_bcast_taps<0>(t), t1 = quad_bcast_taps<1>(t), t2 = quad_bcast_taps<2>(t);
+                scatter_plane(T.gfeat, T.ttile, t0, wk, act, dxg, lane, C.lines);
+                scatter_plane(T.gfeat + T.fplane, T.ttile, t1, wk, act, dxg, lane, C.lines);
+                scatter_plane(T.gfeat + 2 * T.fplane, T.ttile, t2, wk, act, dxg, lane, C.lines);
+            }
+        }
     }
+    __builtin_amdgcn_s_setprio(0);
 }
 
 // stage image b's MLP weights (forward + transposed sections), biases and part / canonical frames into LDS
@@ -771,7 +840,7 @@ __global__ __launch_bounds__(256, 1) void weight_grad_partial_kernel(const Weigh
             f32x4 a1[4], a2[4], o, dz2[4], dz1[4];
             float dxm[8];
             mlp_tile_f32_keep(l_w, l_bias, x, lane, a1, a2, o);
-            mlp_bwd_tile_f32(l_wt, a1, a2, dz3v, lane, dz2, dz1, dxm);
+            mlp_bwd_tile_f32<false>(l_wt, a1, a2, dz3v, lane, dz2, dz1, dxm);
             (void)o; (void)dxm;
 #pragma unroll
             for (int ob = 0; ob < 4; ++ob) { s2[ob] += dz2[ob]; s1[ob] += dz1[ob]; }

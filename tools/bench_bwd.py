@@ -47,6 +47,7 @@ parts, pack = ops.prepare(d["pose_to_camera"], d["bone_length"], cbl.to(dev), d[
 feat_cl = ops.triplane_pack(tri)
 fwd = ops.render_fwd(coord, d["inv_intrinsics"], parts, cpose.to(dev), tri, feat_cl, pack, Nc, Nf, seed=1, mlp_mode="f16x3", return_bins=True)
 bins = fwd.taps["bins"]
+torch.manual_seed(0)          # the same output gradients for every build: |grad_tri| is comparable across variants
 gc, gm = torch.randn(B, 3, n, device=dev), torch.randn(B, n, device=dev)
 cpose_d = cpose.to(dev)
 
