@@ -231,6 +231,7 @@ struct Taps {
     float w00, w01, w10, w11;      // weights, zeroed for out-of-bounds taps
     int xe;                        // x edge: 0 = x0, x0 + 1 both in the plane; 1 = x0 left of it (o00 == o01, column 0);
                                    // 2 = x1 right of it (o00 == o01, column W - 1). Only meaningful for x0 in [-1, W - 1].
+    int yp;                        // parity of the (clamped) upper texel row: the lower row has the other one (backward's walkers)
 };
 __host__ __device__ __forceinline__ Taps make_taps(float x, float y, int H, int W) {
     Taps t;
@@ -257,6 +258,7 @@ __host__ __device__ __forceinline__ Taps make_taps(float x, float y, int H, int 
     t.w10 = zx0 * zy1;
     t.w11 = zx1 * zy1;
     t.xe = (x0 < 0) ? 1 : (x1 >= W) ? 2 : 0;
+    t.yp = cy0 & 1;
     return t;
 }
 // The same taps for coordinates of a VALID (part, point) pair, i.e. |x| < 1 and |y| < 1 strictly (narf.py:201), with half
@@ -292,6 +294,7 @@ __host__ __device__ __forceinline__ Taps make_taps_valid(float x, float y, int H
     t.w10 = zx0 * zy1;
     t.w11 = zx1 * zy1;
     t.xe = (x0 < 0) ? 1 : (x1 >= W) ? 2 : 0;
+    t.yp = cy0 & 1;
     return t;
 }
 // The two taps of one row of a scalar (fp32, row-major) plane with ONE 8-byte load: x0 and x0 + 1 are adjacent floats.

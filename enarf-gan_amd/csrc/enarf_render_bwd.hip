@@ -14,6 +14,9 @@
 #include "enarf_march.h"
 #include "enarf_host.h"
 
+#ifndef ENARF_BWD_PARITY_WALK          // 0 = round 2's walkers by tap slot (A/B)
+#define ENARF_BWD_PARITY_WALK 1
+#endif
 #ifndef ENARF_BWD_NS_FIXED
 #define ENARF_BWD_NS_FIXED 0
 #endif
@@ -60,6 +63,14 @@ __device__ __forceinline__ void scatter_tap2(float *__restrict__ gpl, float *til
                                              bool on, const float dxg[8], int lane, unsigned &n_lines) {
     const int q = lane >> 2, g = lane & 3;
     int *toff = reinterpret_cast<int *>(tile + 2 * 16 * kTRow);
+    // Which half-wave walks which tap: by the PARITY of the texel offset, not by the tap slot. The two taps of a row are
+    // x0 and x0 + 1 - their offsets always differ in parity - so every occurrence of a texel lands with the same walker, and a
+    // sample's x0 + 1 meeting the next sample's x0 (the ray advanced by one texel) is one run instead of two atomics:
+    // 686 -> 613 B of feature lines per valid pair (tests/analysis/atomic_merge.py), what the 6x6 LDS window bought at 2-3x the time.
+    if (ENARF_BWD_PARITY_WALK && (offA & 1)) {
+        const int to = offA; offA = offB; offB = to;
+        const float tc = cfA; cfA = cfB; cfB = tc;
+    }
     const bool liveA = on && cfA != 0.0f, liveB = on && cfB != 0.0f;
     float *rowA = tile + q * kTRow + 8 * g, *rowB = rowA + 16 * kTRow;      // 33-float rows: b32 stores
 #pragma unroll
@@ -96,8 +107,14 @@ __device__ __forceinline__ void scatter_tap2(float *__restrict__ gpl, float *til
 }
 __device__ __forceinline__ void scatter_plane(float *__restrict__ gpl, float *tile, const Taps &t, float wk, bool on,
                                               const float dxg[8], int lane, unsigned &n_lines) {
-    scatter_tap2(gpl, tile, t.o00, t.w00 * wk, t.o01, t.w01 * wk, on, dxg, lane, n_lines);
-    scatter_tap2(gpl, tile, t.o10, t.w10 * wk, t.o11, t.w11 * wk, on, dxg, lane, n_lines);
+    // The two walks of a plane are dealt by the PARITY of the texel ROW (the footprint's rows y0 and y0 + 1 always differ in
+    // it), as the two walkers inside a walk are dealt by the parity of the offset: each of the footprint's four texels then
+    // has ONE walker that sees every occurrence of it, and along a ray - which crosses texels monotonically - those are
+    // consecutive samples: run merging alone removes every duplicate of the tile (tests/analysis/atomic_merge.py: "tile
+    // uniq"), with no LDS table.
+    const bool up = !ENARF_BWD_PARITY_WALK || t.yp == 0;      // the upper row (y0) is the even one
+    scatter_tap2(gpl, tile, up ? t.o00 : t.o10, (up ? t.w00 : t.w10) * wk, up ? t.o01 : t.o11, (up ? t.w01 : t.w11) * wk, on, dxg, lane, n_lines);
+    scatter_tap2(gpl, tile, up ? t.o10 : t.o00, (up ? t.w10 : t.w00) * wk, up ? t.o11 : t.o01, (up ? t.w11 : t.w01) * wk, on, dxg, lane, n_lines);
 }
 
 
@@ -356,8 +373,15 @@ __device__ __forceinline__ void bwd_backward_tile(const QueryCtx &S, const BwdTi
                         const int o0 = quad_bcast_i<PL>(t.o00), o1 = quad_bcast_i<PL>(t.o01), o2 = quad_bcast_i<PL>(t.o10), o3 = quad_bcast_i<PL>(t.o11); \
                         const float w0 = quad_bcast_f<PL>(t.w00), w1 = quad_bcast_f<PL>(t.w01), w2 = quad_bcast_f<PL>(t.w10), w3 = quad_bcast_f<PL>(t.w11); \
                         const float gp = quad_bcast_f<PL>(gm);                                                                 \
-                        const int o = (g4 == 0) ? o0 : (g4 == 1) ? o1 : (g4 == 2) ? o2 : o3;                                   \
-                        const float w = (g4 == 0) ? w0 : (g4 == 1) ? w1 : (g4 == 2) ? w2 : w3;                                 \
+                        /* lane role = (row parity g4 >> 1, offset parity g4 & 1): the footprint texel with those parities - every  \
+                           occurrence of a texel meets the same lane role, so runs along the samples merge ALL its duplicates */      \
+                        const int ypb = quad_bcast_i<PL>(t.yp);                                                                \
+                        const bool r1 = ENARF_BWD_PARITY_WALK ? (ypb != (g4 >> 1)) : (g4 >> 1) != 0;                            \
+                        const int oA = r1 ? o2 : o0, oB = r1 ? o3 : o1;                                                        \
+                        const float wA = r1 ? w2 : w0, wB = r1 ? w3 : w1;                                                      \
+                        const bool tb = ENARF_BWD_PARITY_WALK ? ((oA & 1) != (g4 & 1)) : (g4 & 1) != 0;                         \
+                        const int o = tb ? oB : oA;                                                                            \
+                        const float w = tb ? wB : wA;                                                                          \
                         if (ENARF_BWD_MASK_ROWMAJOR)                                                                           \
                             mask_tap_add_rowmajor(T.gmask, mon && w != 0.0f, (3 * k + PL) * (int)T.mplane + o, w * gp, lane, C.mask_adds); \
                         else                                                                                                   \
@@ -369,7 +393,8 @@ __device__ __forceinline__ void bwd_backward_tile(const QueryCtx &S, const BwdTi
 #undef ENARF_MASK_PLANE
                 }
                 // every lane takes part (wave-uniform): inactive quads contribute empty rows
-                const Taps t0 = quad_bcast_taps<0>(t), t1 = quad_bcast_taps<1>(t), t2 = quad_bcast_taps<2>(t);
+                Taps t0 = quad_bcast_taps<0>(t), t1 = quad_bcast_taps<1>(t), t2 = quad_bcast_taps<2>(t);
+                t0.yp = quad_bcast_i<0>(t.yp); t1.yp = quad_bcast_i<1>(t.yp); t2.yp = quad_bcast_i<2>(t.yp);
                 scatter_plane(T.gfeat, T.ttile, t0, wk, act, dxg, lane, C.lines);
                 scatter_plane(T.gfeat + T.fplane, T.ttile, t1, wk, act, dxg, lane, C.lines);
                 scatter_plane(T.gfeat + 2 * T.fplane, T.ttile, t2, wk, act, dxg, lane, C.lines);

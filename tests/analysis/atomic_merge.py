@@ -2,6 +2,8 @@
 FINE samples of a band of rays, under different on-chip merging schemes. Behind DESIGN.md 3.4. Counts per (part, plane):
   loads       4 taps x valid samples (no merging)
   slot runs   per tap slot, runs of consecutive samples of the tile that hit the same texel (the round-2 kernel)
+  parity runs the two taps of a texel ROW dealt to two walkers by the parity of the texel's offset (x0 and x0 + 1 always
+              differ in it), each walker merging runs of equal texels: catches a sample's x0 + 1 meeting the next sample's x0
   tile uniq   distinct texels over the 4 taps x 16 samples of a tile (an LDS table per tile and part)
   ray uniq    distinct texels over the whole ray (an LDS table per ray and part)
 Run: python tests/analysis/atomic_merge.py [first_ray n_rays]"""
@@ -29,7 +31,7 @@ can = can[0].reshape(23, 3, n, N).numpy()
 v = taps["fine_valid"][0].numpy().astype(bool)
 v[:, :, N - 1] = False                      # the last fine sample carries no weight (rendering.py:307-321)
 W = 256
-loads = slot_runs = tile_uniq = ray_uniq = 0
+loads = slot_runs = tile_uniq = ray_uniq = parity_runs = 0
 mask_loads = mask_runs = 0
 for (a, b) in [(0, 1), (1, 2), (2, 0)]:
     ix = ((can[:, a] + 1) * W - 1) / 2; iy = ((can[:, b] + 1) * W - 1) / 2
@@ -47,11 +49,16 @@ for (a, b) in [(0, 1), (1, 2), (2, 0)]:
                 loads += 4 * ff.size
                 runs = 1 + int((np.diff(ff) != 0).sum())
                 slot_runs += 4 * runs
+                for row in (0, 1024):                       # texel rows y0 and y0 + 1, each walked by two parity walkers
+                    for par in (0, 1):
+                        seq = np.where(((ff + row) & 1) == par, ff + row, ff + row + 1)      # the row's tap of that parity
+                        parity_runs += 1 + int((np.diff(seq) != 0).sum())
                 tile_uniq += np.unique(np.concatenate([ff, ff + 1, ff + 1024, ff + 1025])).size
             ffr = f[vk]
             ray_uniq += np.unique(np.concatenate([ffr, ffr + 1, ffr + 1024, ffr + 1025])).size
 pairs = int(v.sum())
 print(f"rays {n} (from {r0}), valid fine pairs {pairs}")
+print(f"parity runs {parity_runs} ({loads / parity_runs:.2f}x, {parity_runs * 128 / pairs:.0f} B per pair)")
 print(f"feature line-adds: loads {loads} | slot runs {slot_runs} ({loads / slot_runs:.2f}x) | tile uniq {tile_uniq} ({loads / tile_uniq:.2f}x) | "
       f"ray uniq {ray_uniq} ({loads / ray_uniq:.2f}x)")
 print(f"bytes per pair: loads {loads * 128 / pairs:.0f} | slot runs {slot_runs * 128 / pairs:.0f} | tile uniq {tile_uniq * 128 / pairs:.0f} | ray uniq {ray_uniq * 128 / pairs:.0f}")
