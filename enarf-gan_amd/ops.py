@@ -619,8 +619,7 @@ def render_bwd(image_coord, inv_intrinsics, parts, canonical_pose, tri_nchw, fea
     dev = coord.device
     rows = int(lib.enarf_render_bwd_rows_per_image(n, Nf))
     bufs, blocks = _row_buffers(B, rows, dev)
-    grad_tri = torch.zeros_like(tri)
-    gfeat = torch.zeros_like(feat_cl)
+    grad_tri, gfeat = _zeros_pair(tri, feat_cl)
     a = _lib.RenderBwdArgs()
     a.B, a.n, a.P, a.Nf, a.H, a.W = B, n, P, Nf, H, W
     a.drop_invalid_rays = int(B == 1 if drop_invalid_rays is None else drop_invalid_rays)
@@ -659,6 +658,19 @@ def render_bwd(image_coord, inv_intrinsics, parts, canonical_pose, tri_nchw, fea
     return grad_tri, dW, db
 
 
+def _zeros_pair(a: torch.Tensor, b: torch.Tensor):
+    """zero-filled tensors shaped like a and b from ONE allocation and one fill launch (the gradient planes of a backward)"""
+    na = (a.numel() + 63) // 64 * 64                      # keeps the second tensor 256-byte aligned
+    buf = torch.zeros(na + b.numel(), dtype=torch.float32, device=a.device)
+    return buf[:a.numel()].view(a.shape), buf[na:].view(b.shape)
+
+
+def _sum_images(t: torch.Tensor) -> torch.Tensor:
+    """per-image gradients of a shared parameter -> the parameter's gradient; one image: a view, not a launch (the 13 such
+    sums of a C1 backward were 57 us of 4 us reduction kernels: profiles/r03_bwd_final_kernel_stats.csv)"""
+    return t[0] if t.shape[0] == 1 else t.sum(dim=0)
+
+
 def _row_buffers(B: int, rows: int, dev: torch.device):
     bufs = {k: torch.empty(B, rows, w, dtype=torch.float32, device=dev) for k, w in (("x", 32), ("dz3", 4))}
     return bufs, torch.zeros(B, dtype=torch.int32, device=dev)
@@ -678,7 +690,7 @@ def _weight_grad(bufs, blocks, mlp_pack, B: int, rows: int, dev: torch.device):
     wws = torch.empty(int(lib.enarf_weight_grad_workspace_bytes(B, rows)) // 4, dtype=torch.float32, device=dev)
     w.workspace = _p(wws)
     _lib.check(lib.enarf_weight_grad(C.byref(w), _stream(dev)), "enarf_weight_grad")
-    return dW, [t.sum(dim=0) for t in dbb]
+    return dW, [_sum_images(t) for t in dbb]
 
 
 @_on_tensor_device
@@ -697,8 +709,7 @@ def query_bwd(points, parts, canonical_pose, tri_nchw, feat_cl, mlp_pack, g_dens
     dev = pts.device
     rows = max(int(lib.enarf_query_bwd_rows_per_image(N)), 16)
     bufs, blocks = _row_buffers(B, rows, dev)
-    grad_tri = torch.zeros_like(tri)
-    gfeat = torch.zeros_like(feat_cl)
+    grad_tri, gfeat = _zeros_pair(tri, feat_cl)
     a = _lib.QueryBwdArgs()
     a.B, a.P, a.H, a.W, a.N = B, P, H, W, N
     a.clamp_mask, a.uniform_part_weight = int(bool(clamp_mask)), int(bool(uniform_part_weight))
@@ -749,7 +760,7 @@ def prepare_bwd(z_rend: torch.Tensor, mlp: Dict[str, torch.Tensor], dW):
     _lib.check(lib.enarf_prepare_bwd(C.byref(a), _stream(dev)), "enarf_prepare_bwd")
     grads = {}
     for i, (cin, cout) in enumerate(dims):
-        grads[f"layers.{i}.conv.weight"] = outs[i][0].sum(0).reshape(1, cout, cin, 1)
-        grads[f"layers.{i}.conv.modulation.weight"] = outs[i][1].sum(0)
-        grads[f"layers.{i}.conv.modulation.bias"] = outs[i][2].sum(0)
+        grads[f"layers.{i}.conv.weight"] = _sum_images(outs[i][0]).reshape(1, cout, cin, 1)
+        grads[f"layers.{i}.conv.modulation.weight"] = _sum_images(outs[i][1])
+        grads[f"layers.{i}.conv.modulation.bias"] = _sum_images(outs[i][2])
     return grads, dz.sum(1)
