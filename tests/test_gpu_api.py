@@ -334,3 +334,31 @@ def test_forward_return_intermediate_gives_fine_points_and_density():
         m.train()
         m(1, coord.cuda(), s["pose_to_camera"].cuda(), s["inv_intrinsics"].cuda(), None, s["z_rend"].cuda(),
           s["bone_length"].cuda(), Nc=24, Nf=32, return_intermediate=True)
+
+
+def test_sampler_image_ids_outside_the_batch_sample_nothing():
+    """enarf_triplane_sample_ex_fwd / _bwd with a per-point image index (sample_feature's batch_idx, sampling.py:34-38): an
+    id outside [0, n_images) - negative included - samples zeros and receives / sends no gradient, as a position in the
+    reference's zero padding would; it must not become an out-of-bounds read or atomic. In-range points are
+    unchanged by the presence of the others."""
+    from enarf_gan_amd import ops
+    g = torch.Generator().manual_seed(9)
+    inp = torch.randn(3, 3 * 8, 16, 20, generator=g).cuda()
+    n = 500
+    grid = (torch.rand(1, n, 3, generator=g) * 2 - 1).cuda()
+    ids = torch.randint(0, 3, (n,), generator=g, dtype=torch.int32)
+    bad = ids.clone()
+    bad[::7] = 3
+    bad[3::11] = -1
+    bad[5::13] = 1 << 30
+    off = ((bad < 0) | (bad >= 3)).cuda()
+    ref = ops.triplane_sample_ex_fwd(inp, grid, point_image=ids.cuda())
+    out = ops.triplane_sample_ex_fwd(inp, grid, point_image=bad.cuda())
+    assert float(out[..., off].abs().max()) == 0.0 and torch.equal(out[..., ~off], ref[..., ~off])
+    sep = ops.triplane_sample_ex_fwd(inp, grid, separate=True, point_image=bad.cuda())
+    assert float(sep[..., off].abs().max()) == 0.0
+    go = torch.randn(1, 8, n, generator=g).cuda()
+    gi, gg = ops.triplane_sample_ex_bwd(go, inp, grid, False, bad.cuda(), True, True)
+    gi_ref, gg_ref = ops.triplane_sample_ex_bwd(go * (~off).float(), inp, grid, False, ids.cuda(), True, True)
+    assert float(gg[0, off].abs().max()) == 0.0 and torch.equal(gg[0, ~off], gg_ref[0, ~off])
+    assert_close(gi.cpu(), gi_ref.cpu(), "grad_input with out-of-batch ids", 1e-6)
