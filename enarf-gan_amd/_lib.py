@@ -27,7 +27,7 @@ def library_info() -> dict:
     """What is (or will be) loaded: path and whether it is a variant build - bench.py prints this."""
     return {"path": LIB_PATH, "variant": _variant}
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 STATUS_MARCH_WATCHDOG = 1                      # ENARF_STATUS_* (include/enarf_hip.h)
 MAX_JOINTS = 32
 MAX_PARTS = 32
@@ -173,6 +173,10 @@ SIGNATURES = {
     "enarf_mask_topk_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "enarf_mask_dilate_topk": (C.c_int, [_f32p, _f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                          C.c_void_p]),
+    "enarf_bias_act": (C.c_int, [_f32p, _f32p, _f32p, _f32p, C.c_longlong, C.c_int, C.c_longlong, C.c_float, C.c_float, C.c_void_p]),
+    "enarf_upfirdn2d_out_size": (C.c_int, [C.c_int] * 6),
+    "enarf_upfirdn2d": (C.c_int, [_f32p, _f32p, C.c_longlong, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int, C.c_int,
+                                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
 }
 
 _lib: Optional[C.CDLL] = None

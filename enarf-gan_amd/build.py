@@ -14,7 +14,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(CSRC, "libenarf_hip.so")
-SOURCES = ["enarf_render.hip", "enarf_render_bwd.hip", "enarf_sampler.hip", "enarf_raysample.hip"]
+SOURCES = ["enarf_render.hip", "enarf_render_bwd.hip", "enarf_sampler.hip", "enarf_raysample.hip", "enarf_gan_ops.hip"]
 # every header next to the sources is a dependency of every object (a list by name went stale when enarf_tasks.h was added)
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join(ROOT, "include", "enarf_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",

@@ -4,9 +4,9 @@ They keep the constructor arguments, method names, argument order and return tup
 `models/generator.py` (TriNARFGenerator :14-118, DSONARFGenerator :182-300) so that its train / demo scripts can switch
 over; everything inside is this package's own plumbing around `TriPlaneNARF`.
 
-Out of scope: the StyleGAN2 background network. Render on black (`black_background=True` or
-`black_bg_if_possible=True`), or assign `gen.background_generator` - any module called as
-`bg([z_background, z_render], inject_index=bg.n_latent - 4) -> (image, _)`.
+The background network is the StyleGAN2 skip generator of `libraries/custom_stylegan2/net.py` (generator.py:32-38:
+n_mlp 4, `crop_background` from the config, or the pretrained church generator), built on this repo's HIP ops; with
+`black_background=True` / `black_bg_if_possible=True` nothing of it runs.
 """
 from typing import Optional
 
@@ -14,6 +14,8 @@ import numpy as np
 import torch
 from torch import nn
 
+from ..libraries.custom_stylegan2.net import Generator as StyleGANGenerator
+from ..libraries.custom_stylegan2.net import PretrainedStyleGAN
 from ..libraries.NeRF.ray_sampler import mask_based_sampler, whole_image_grid_ray_sampler
 from .narf import TriPlaneNARF
 
@@ -53,7 +55,13 @@ class TriNARFGenerator(_RendererShell):
         self.ray_sampler = whole_image_grid_ray_sampler
         self.background_ratio = config.background_ratio
         self.black_background = black_background
-        self.background_generator = None          # not rebuilt here - see the module docstring
+        self.background_generator = None
+        if not black_background:                   # generator.py:32-38
+            if config.pretrained_background:
+                self.background_generator = PretrainedStyleGAN()
+            else:
+                self.background_generator = StyleGANGenerator(size=size, style_dim=config.z_dim, n_mlp=4, last_channel=3,
+                                                              crop_background=config.crop_background)
 
     def normalized_inv_intrinsics(self, intrinsics: torch.Tensor):
         bottom = intrinsics.new_tensor([[0, 0, 1]])
@@ -70,9 +78,6 @@ class TriNARFGenerator(_RendererShell):
         if self.black_background or force_black:
             return -1
         bg = self.background_generator
-        if bg is None:
-            raise NotImplementedError("the StyleGAN2 background generator is out of scope: assign "
-                                      "gen.background_generator, or use black_background / black_bg_if_possible")
         image, _ = bg([z_bg, z_render], inject_index=bg.n_latent - 4)
         return image
 

@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define ENARF_ABI_VERSION 3
+#define ENARF_ABI_VERSION 4
 
 #define ENARF_ERR_ARG          (-1)   /* null pointer / non-positive size / bad enum */
 #define ENARF_ERR_UNSUPPORTED  (-2)   /* valid in the reference but not implemented here (message says what) */
@@ -421,6 +421,27 @@ int enarf_triplane_warp_bwd(const float *g_out_cl, const float *src_cl, const fl
 size_t enarf_mask_topk_workspace_bytes(int B, int h, int w);
 int enarf_mask_dilate_topk(const float *mask, const float *noise, long long *out_idx, int B, int h, int w, int k, int radius,
                            void *workspace, enarf_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * the two element-level ops of the reference's 2-D GAN networks (discriminator, background
+ * generator: libraries/custom_stylegan2/net.py:346-676). The reference imports them from an un-vendored submodule
+ * (net.py:12-14: FusedLeakyReLU / fused_leaky_relu, Blur / Upsample of rosinality/stylegan2-pytorch, CUDA extensions
+ * `fused_bias_act` and `upfirdn2d`); these entry points are what that import would bind instead.
+ *
+ * enarf_bias_act: x, out contiguous (outer, C, inner) fp32.
+ *   ref == NULL:  out = gain * leaky_relu(x + bias[c], negative_slope)       (bias may be NULL)
+ *   ref != NULL:  out = x * gain * (ref > 0 ? 1 : negative_slope)            (ref = the forward OUTPUT; the derivative of the
+ *                 line above with respect to x applied to x - and, being linear in x, its own derivative too)
+ * enarf_upfirdn2d: x (planes, H, W) -> out (planes, OH, OW): insert up - 1 zeros after every sample, pad by
+ *   (pad_*0, pad_*1) (negative = crop), convolve with the kh x kw filter `kernel_host` (HOST memory, row-major, <= 8 x 8; a
+ *   true convolution: the filter is flipped), keep every down-th sample. OH = enarf_upfirdn2d_out_size(H, kh, up, down,
+ *   pad_y0, pad_y1) = (H * up + pad_y0 + pad_y1 - kh) / down + 1. Built for up / down in {1/1, 2/1, 1/2}.
+ * --------------------------------------------------------------------------------------------- */
+int enarf_bias_act(const float *x, const float *bias, const float *ref, float *out, long long outer, int C, long long inner,
+                   float negative_slope, float gain, enarf_stream_t stream);
+int enarf_upfirdn2d_out_size(int in_size, int taps, int up, int down, int pad0, int pad1);
+int enarf_upfirdn2d(const float *x, float *out, long long planes, int H, int W, const float *kernel_host, int kh, int kw,
+                    int up, int down, int pad_x0, int pad_x1, int pad_y0, int pad_y1, enarf_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,225 @@
+"""GPU tests of SURVEY.md 8(f) rank 4: the HIP ops under the 2-D GAN networks against a plain PyTorch fp32 / the oracle's
+restatement (forward, backward, second derivative), the mirror discriminator and background generator against the
+imported reference's outputs (tests/golden/gan2d_*.npz), and one whole GAN step through renderer + discriminator."""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from _helpers import Scene
+from oracle import gan_ops_oracle as third
+from test_host_cpu import Cfg, _nerf_cfg
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _rel(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+# ------------------------------------------------------------------------------------------------ bias + leaky ReLU
+@pytest.mark.parametrize("shape", [(4, 16, 32, 32), (3, 7, 5, 5), (2, 5, 9), (6, 33), (1, 512, 4, 4), (2, 3, 1, 1030)])
+def test_fused_leaky_relu_forward_backward_and_second_derivative(shape):
+    from enarf_gan_amd.libraries.custom_stylegan2 import op
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(shape, generator=g)
+    b = torch.randn(shape[1], generator=g)
+    gy = torch.randn(shape, generator=g)
+    ggx = torch.randn(shape, generator=g)
+
+    def run(fn, dev):
+        xx, bb = x.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+        y = fn(xx, bb, 0.2, 2 ** 0.5)
+        gx, gb = torch.autograd.grad(y, [xx, bb], gy.to(dev), create_graph=True)
+        # second derivative: d <gx, ggx> / d (grad_output) is what R1's backward needs; take it w.r.t. an upstream scale
+        s = torch.ones((), device=dev, requires_grad=True)
+        y2 = fn(xx * s, bb, 0.2, 2 ** 0.5)
+        (g1,) = torch.autograd.grad(y2, xx, gy.to(dev), create_graph=True)
+        (g2,) = torch.autograd.grad((g1 * ggx.to(dev)).sum(), s)
+        return y.detach().cpu(), gx.detach().cpu(), gb.detach().cpu(), g2.cpu()
+
+    want = run(third.fused_leaky_relu, "cpu")
+    got = run(op.fused_leaky_relu, "cuda")
+    assert torch.equal(got[0], want[0].float()) or _rel(got[0], want[0]) < 1e-6
+    assert _rel(got[1], want[1]) < 1e-6
+    assert _rel(got[2], want[2]) < 1e-5          # a sum over outer x inner terms in another order
+    assert _rel(got[3], want[3]) < 1e-5
+
+
+def test_fused_leaky_relu_module_and_no_bias():
+    from enarf_gan_amd.libraries.custom_stylegan2 import op
+    m = op.FusedLeakyReLU(8).cuda()
+    with torch.no_grad():
+        m.bias.copy_(torch.linspace(-1, 1, 8))
+    x = torch.randn(2, 8, 6, 6, device="cuda")
+    torch.testing.assert_close(m(x), F.leaky_relu(x + m.bias.view(1, 8, 1, 1), 0.2) * 2 ** 0.5)
+    torch.testing.assert_close(op.fused_leaky_relu(x), F.leaky_relu(x, 0.2) * 2 ** 0.5)
+    # a non-contiguous input is taken as it is meant (the wrapper makes it dense)
+    xt = x.permute(0, 1, 3, 2)
+    torch.testing.assert_close(op.fused_leaky_relu(xt, m.bias), F.leaky_relu(xt + m.bias.view(1, 8, 1, 1), 0.2) * 2 ** 0.5)
+
+
+# ------------------------------------------------------------------------------------------------------ upfirdn2d
+UPFIRDN_CASES = [(1, 1, (2, 1)), (1, 1, (1, 1)), (2, 1, (2, 1)), (1, 2, (2, 2)), (1, 2, (1, 1)), (1, 1, (-1, 2)), (1, 1, (0, 0, 3, -1)),
+                 (2, 1, (0, 0)), (1, 2, (0, 3, 1, 0)), (2, 1, (3, 3)), (1, 2, (5, 4))]
+
+
+@pytest.mark.parametrize("up,down,pad", UPFIRDN_CASES)
+@pytest.mark.parametrize("hw", [(9, 13), (64, 64), (33, 130), (128, 128)])
+def test_upfirdn2d_matches_restatement(up, down, pad, hw):
+    from enarf_gan_amd.libraries.custom_stylegan2 import op
+    H, W = hw
+    g = torch.Generator().manual_seed(H * 1000 + W + up * 7 + down)
+    x = torch.randn(2, 3, H, W, generator=g)
+    k = torch.outer(torch.tensor([1.0, 3.0, 3.0, 1.0]), torch.tensor([1.0, 2.0, -1.0])) / 7.0          # asymmetric 4 x 3
+    want = third.upfirdn2d(x.double(), k.double(), up=up, down=down, pad=pad)
+    got = op.upfirdn2d(x.cuda(), k.cuda(), up=up, down=down, pad=pad)
+    assert got.shape == want.shape
+    assert _rel(got, want) < 2e-6
+
+
+@pytest.mark.parametrize("up,down,pad", [(1, 1, (2, 1)), (2, 1, (2, 1)), (1, 2, (2, 2)), (1, 1, (-1, 2)), (1, 2, (1, 1))])
+def test_upfirdn2d_backward_and_second_derivative(up, down, pad):
+    from enarf_gan_amd.libraries.custom_stylegan2 import op
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 2, 21, 18, generator=g)
+    k = op.make_kernel([1, 3, 3, 1]) * (up ** 2)
+
+    def run(fn, dev, dt):
+        xx = x.to(dev, dt).requires_grad_(True)
+        y = fn(xx, k.to(dev, dt), up=up, down=down, pad=pad)
+        gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(5)).to(dev, dt)
+        # a non-linear function of the op's output, so that the second derivative is not zero
+        (gx,) = torch.autograd.grad((y * y * gy).sum(), xx, create_graph=True)
+        (ggx,) = torch.autograd.grad(gx.pow(2).sum(), xx)
+        return y.detach().cpu(), gx.detach().cpu(), ggx.cpu()
+
+    want = run(third.upfirdn2d, "cpu", torch.float64)
+    got = run(op.upfirdn2d, "cuda", torch.float32)
+    for a, b, tol in zip(got, want, (2e-6, 1e-5, 1e-4)):
+        assert a.shape == b.shape and _rel(a, b) < tol
+
+
+def test_upfirdn2d_many_planes_and_modules():
+    """more planes than one grid axis holds (the launch strides over them), and the Blur / Upsample modules"""
+    from enarf_gan_amd.libraries.custom_stylegan2 import op
+    x = torch.randn(70000, 1, 8, 8, generator=torch.Generator().manual_seed(1))
+    k = op.make_kernel([1, 3, 3, 1])
+    got = op.upfirdn2d(x.cuda(), k.cuda(), pad=(2, 1))
+    want = third.upfirdn2d(x, k, pad=(2, 1))
+    assert _rel(got, want) < 2e-6
+    y = torch.randn(2, 4, 16, 16, generator=torch.Generator().manual_seed(2))
+    assert _rel(op.Blur([1, 3, 3, 1], pad=(2, 2)).cuda()(y.cuda()), third.Blur([1, 3, 3, 1], pad=(2, 2))(y)) < 2e-6
+    up = op.Upsample([1, 3, 3, 1]).cuda()(y.cuda())
+    assert up.shape == (2, 4, 32, 32) and _rel(up, third.Upsample([1, 3, 3, 1])(y)) < 2e-6
+    # a constant image stays constant under the up-sampler (unit DC gain after the factor^2 scaling), away from the border
+    c = op.Upsample([1, 3, 3, 1]).cuda()(torch.full((1, 1, 8, 8), 3.0, device="cuda"))
+    torch.testing.assert_close(c[:, :, 2:-2, 2:-2], torch.full((1, 1, 12, 12), 3.0, device="cuda"))
+    with pytest.raises(Exception):
+        op.upfirdn2d(y.cuda(), k.cuda(), up=2, down=2)
+
+
+# ---------------------------------------------------------------------------------------- networks vs the reference
+@pytest.mark.parametrize("name", ["gan2d_dis_32_std", "gan2d_dis_16_nostd"])
+def test_discriminator_matches_reference_golden(name):
+    from enarf_gan_amd.libraries.custom_stylegan2 import net
+    from enarf_gan_amd.libraries.gan.loss import d_r1_loss
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    dis = net.Discriminator(SimpleNamespace(minibatch_std=bool(g["minibatch_std"])), size=int(g["size"]))
+    third.fill_by_name(dis)                         # the weights of the fixture: a function of the state-dict keys
+    dis = dis.cuda()
+    x = torch.from_numpy(g["x"]).cuda().requires_grad_(True)
+    out = dis(x)
+    assert out.shape == g["out"].shape
+    assert _rel(out.detach(), g["out"]) < 2e-4
+    r1 = d_r1_loss(out, x)
+    (gx,) = torch.autograd.grad(out.sum(), x, retain_graph=True)
+    assert _rel(gx, g["grad_x"]) < 2e-4
+    assert abs(float(r1) - float(g["r1"])) < 2e-4 * abs(float(g["r1"]))
+    g_lin, g_first = torch.autograd.grad(r1, [dis.final_linear[1].weight, dis.convs[0][0].weight])
+    assert _rel(g_lin, g["r1_grad_final_linear_1_weight"]) < 5e-4          # second derivatives through every HIP op
+    assert _rel(g_first, g["r1_grad_convs_0_0_weight"]) < 5e-4
+
+
+@pytest.mark.parametrize("name", ["gan2d_gen_32_crop", "gan2d_gen_16"])
+def test_background_generator_matches_reference_golden(name):
+    from enarf_gan_amd.libraries.custom_stylegan2 import net
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    gen = net.Generator(size=int(g["size"]), style_dim=int(g["style_dim"]), n_mlp=4, last_channel=3,
+                        crop_background=bool(g["crop_background"]))
+    third.fill_by_name(gen)
+    gen = gen.cuda().eval()
+    noise = [torch.from_numpy(g[f"noise_{i}"]).cuda() for i in range(gen.num_layers)]
+    z_bg, z_r = torch.from_numpy(g["z_bg"]).cuda(), torch.from_numpy(g["z_render"]).cuda()
+    with torch.no_grad():
+        img, none = gen([z_bg, z_r], inject_index=gen.n_latent - 4, noise=noise)
+        one, lat = gen([z_bg], return_latents=True, noise=noise)
+    assert none is None and img.shape == g["image"].shape
+    assert _rel(img, g["image"]) < 2e-4
+    assert _rel(one, g["image_one_style"]) < 2e-4
+    assert _rel(lat, g["latent_one_style"]) < 1e-5
+    # training mode of the cropped variant: a random window of the same wide image
+    if bool(g["crop_background"]):
+        gen.train()
+        with torch.no_grad():
+            win, _ = gen([z_bg, z_r], inject_index=gen.n_latent - 4, noise=noise)
+        assert win.shape == img.shape and bool(torch.isfinite(win).all())
+
+
+# ----------------------------------------------------------------------------------------------- the GAN loop closed
+def test_one_gan_step_through_renderer_background_and_discriminator():
+    """train_ENARF_GAN.py:102-170 in small: generator forward (HIP renderer + background generator), generator loss through
+    the discriminator, backward to the renderer's parameters and the background generator's; discriminator loss and the R1
+    step. Checks the composite (generator.py:107) and that every parameter group receives a finite, non-zero gradient."""
+    from enarf_gan_amd.libraries.custom_stylegan2 import net
+    from enarf_gan_amd.libraries.gan.loss import adv_loss_dis, adv_loss_gen, d_r1_loss
+    from enarf_gan_amd.models.generator import TriNARFGenerator
+    S, B, Nc, Nf, zd = 32, 2, 24, 32, 32
+    sc = Scene(S, B, "center_fixed", zd)
+    torch.manual_seed(0)
+    gen = TriNARFGenerator(Cfg(z_dim=zd, background_ratio=0.7, crop_background=True, pretrained_background=False,
+                               nerf_params=_nerf_cfg(Nc=Nc, Nf=Nf, constant_triplane=False)), S, 24, sc.raw["parents"], 23)
+    gen.register_canonical_pose(sc.raw["canonical_pose"])
+    assert isinstance(gen.background_generator, net.Generator) and gen.background_generator.crop_background
+    gen = gen.cuda().train()
+    tri = sc.raw["tri_plane"].cuda().requires_grad_(True)            # stands in for the un-vendored tri-plane synthesis net
+    gen.nerf.tri_plane_gen = lambda z, enc, truncation_psi=1: tri
+    dis = net.Discriminator(SimpleNamespace(minibatch_std=True), size=S).cuda()
+    s = sc.raw
+    z = torch.randn(B, 4 * zd, device="cuda")
+    # generator step
+    dis.requires_grad_(False)
+    gen.eval()                 # the centre window of the background and, with the same seed, the same importance samples
+    with torch.no_grad():
+        torch.manual_seed(1)
+        fg, fg_mask, bg = gen(s["pose_to_camera"].cuda(), None, s["bone_length"].cuda(), z, s["inv_intrinsics"].cuda(), return_bg=True)
+        torch.manual_seed(1)
+        whole, mask_e, _, _ = gen(s["pose_to_camera"].cuda(), None, s["bone_length"].cuda(), z, s["inv_intrinsics"].cuda())
+    assert bg.shape == (B, 3, S, S) and torch.equal(mask_e, fg_mask)
+    torch.testing.assert_close(whole, fg + (1 - fg_mask[:, None]) * bg)              # generator.py:107
+    gen.train()
+    fake, mask, _, _ = gen(s["pose_to_camera"].cuda(), None, s["bone_length"].cuda(), z, s["inv_intrinsics"].cuda())
+    assert fake.shape == (B, 3, S, S) and float(mask.max()) > 0.2
+    loss_g = adv_loss_gen(dis(fake), "ce")
+    loss_g.backward()
+    groups = {"tri-plane": tri.grad, "StyledMLP": gen.nerf.mlp.layers[0].conv.weight.grad,
+              "background": gen.background_generator.convs[0].conv.weight.grad,
+              "background style": gen.background_generator.style[1].weight.grad}
+    for name, gr in groups.items():
+        assert gr is not None and bool(torch.isfinite(gr).all()) and float(gr.abs().max()) > 0, name
+    assert all(p.grad is None for p in dis.parameters())
+    # discriminator step + R1
+    dis.requires_grad_(True)
+    real = torch.randn(B, 3, S, S, device="cuda").requires_grad_(True)
+    loss_d = adv_loss_dis(dis(real), dis(fake.detach()), "ce")
+    loss_d.backward()
+    r1 = d_r1_loss(dis(real), real)
+    (0.5 * r1 * 16 * 10).backward()
+    for n_, p in dis.named_parameters():
+        assert p.grad is not None and bool(torch.isfinite(p.grad).all()), n_
+    assert float(dis.convs[1].conv2[1].weight.grad.abs().max()) > 0

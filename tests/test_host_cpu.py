@@ -27,7 +27,7 @@ def test_header_symbols_all_exported_and_bound():
         assert hasattr(lib, name), f"{name} declared in enarf_hip.h but not exported by libenarf_hip.so"
         assert name in _lib.SIGNATURES, f"{name} has no ctypes signature in _lib.py"
     assert set(_lib.SIGNATURES) == set(declared)
-    assert lib.enarf_abi_version() == _lib.ABI_VERSION == 3
+    assert lib.enarf_abi_version() == _lib.ABI_VERSION == 4
     assert lib.enarf_mlp_pack_bytes() % 16 == 0
 
 
