@@ -53,52 +53,105 @@ __global__ __launch_bounds__(256) void bias_act_kernel(const float *__restrict__
 // ---- upfirdn2d ---------------------------------------------------------------------------------------------------------
 // y[oy][ox] = sum_{i, j} kf[i][j] * P[oy * DOWN + i][ox * DOWN + j],  P[u][v] = x[(u - py0) / UP][(v - px0) / UP] where both
 // quotients are exact and inside the image, else 0;  kf = the filter flipped in both axes (a true convolution).
-// One workgroup = a 64 x 16 tile of one plane's output; the input rows / columns the tile can reach go through LDS once.
+// One workgroup = a 64 x 32 tile of one plane's output; the input rows / columns the tile can reach go through LDS once
+// (rows dealt to the waves, columns to the lanes: no index division). A thread owns 8 vertically adjacent outputs of one
+// column. For the 4 x 4 filters the networks use (KH = KW = 4, UP = 1) it slides down its column once: each LDS row it
+// touches is read ONCE into 4 registers and feeds every output whose window holds it - 11 (DOWN = 1) or 18 (DOWN = 2) row
+// reads for 8 outputs instead of 32, everything unrolled, the taps in SGPRs. Other filter sizes and the zero-stuffing
+// up-sampler (which touches 2 x 2 taps per output) take the generic loop.
 constexpr int kUfMaxTaps = 8;                  // filter extent per axis
-constexpr int kUfTW = 64, kUfTH = 16;
-constexpr int kUfRows = kUfTH * 2 + kUfMaxTaps, kUfCols = kUfTW * 2 + kUfMaxTaps;      // the DOWN = 2, UP = 1 worst case
+constexpr int kUfTW = 64;                      // outputs per tile row; a tile is 4 * PER rows (PER vertically adjacent outputs per thread)
 struct UpfirParams {
     const float *x;
     float *y;
     long long planes;
     int H, W, OH, OW, kh, kw, px0, py0;
+    int tstride;                               // floats per row of the LDS tile (sized by the launch for its up / down / filter:
+                                               // a 4-tap blur at down = 1 needs 11 KB, not the 39 KB of the worst case - at 4
+                                               // workgroups per CU the kernel was bound by the bytes it kept in flight)
     float kf[kUfMaxTaps * kUfMaxTaps];         // flipped filter, row-major kh x kw
 };
 __device__ __forceinline__ int floor_div(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
 
-template <int UP, int DOWN>
+template <int UP, int DOWN, int KH, int KW, int PER>          // KH = KW = 0: filter extents at run time
 __global__ __launch_bounds__(256) void upfirdn2d_kernel(const UpfirParams p) {
-    __shared__ float tile[kUfRows][kUfCols + 1];
-    const int tid = threadIdx.x;
+    extern __shared__ float tile[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ts = p.tstride;
+    constexpr int kUfPer = PER, kUfTH = 4 * PER;
+    const int kh = KH ? KH : p.kh, kw = KW ? KW : p.kw;
     const int ox0 = blockIdx.x * kUfTW, oy0 = blockIdx.y * kUfTH;
     // rows / columns of x the tile can reach: u in [oy0 * DOWN, (oy0 + TH - 1) * DOWN + kh - 1], row = (u - py0) / UP
-    const int iy_min = floor_div(oy0 * DOWN - p.py0 + UP - 1, UP), iy_max = floor_div((oy0 + kUfTH - 1) * DOWN + p.kh - 1 - p.py0, UP);
-    const int ix_min = floor_div(ox0 * DOWN - p.px0 + UP - 1, UP), ix_max = floor_div((ox0 + kUfTW - 1) * DOWN + p.kw - 1 - p.px0, UP);
-    const int nr = iy_max - iy_min + 1, nc = ix_max - ix_min + 1;          // <= kUfRows, kUfCols by construction
+    const int iy_min = floor_div(oy0 * DOWN - p.py0 + UP - 1, UP), iy_max = floor_div((oy0 + kUfTH - 1) * DOWN + kh - 1 - p.py0, UP);
+    const int ix_min = floor_div(ox0 * DOWN - p.px0 + UP - 1, UP), ix_max = floor_div((ox0 + kUfTW - 1) * DOWN + kw - 1 - p.px0, UP);
+    const int nr = iy_max - iy_min + 1, nc = ix_max - ix_min + 1;          // <= the launch's tile rows, tstride by construction
+    const int ox = ox0 + lane, oyb = oy0 + wave * kUfPer;
+    // loads per thread that cover the largest tile of this instantiation (filters up to 8 taps)
+    constexpr int MAXR = ((4 * PER - 1) * DOWN + kUfMaxTaps - 1) / UP + 1, MAXC = ((kUfTW - 1) * DOWN + kUfMaxTaps - 1) / UP + 1;
+    constexpr int NLD = (MAXR * MAXC + 255) / 256;
+    const int total = nr * nc;
+    const unsigned magic = (1u << 22) / (unsigned)nc + 1u;          // i / nc == (i * magic) >> 22 for i < 2^22 / nc (i < 9 400, nc <= 134)
     for (long long plane = blockIdx.z; plane < p.planes; plane += gridDim.z) {
         const float *xp = p.x + (size_t)plane * p.H * p.W;
-        for (int i = tid; i < nr * nc; i += 256) {
-            const int r = i / nc, c = i - r * nc, iy = iy_min + r, ix = ix_min + c;
-            tile[r][c] = (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? xp[(size_t)iy * p.W + ix] : 0.0f;
+        // every load of the tile is issued before the first LDS write (a load-then-store loop waits out one memory latency
+        // per row: 0.24 -> 0.40 ms when the tile grew from 35 to 67 rows); flat index over the tile, rows by multiply-shift
+        float stage[NLD];
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int i = tid + 256 * k;
+            const int r = (int)(((unsigned)i * magic) >> 22), c = i - r * nc;
+            const int iy = iy_min + r, ix = ix_min + c;
+            const bool in = i < total && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            stage[k] = in ? xp[(size_t)iy * p.W + ix] : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int i = tid + 256 * k;
+            const int r = (int)(((unsigned)i * magic) >> 22), c = i - r * nc;
+            if (i < total) tile[r * ts + c] = stage[k];
         }
         __syncthreads();
-        const int ox = ox0 + (tid & 63);
+        float *yp = p.y + (size_t)plane * p.OH * p.OW;
+        if (UP == 1 && KH > 0) {
+            const int c0 = ox * DOWN - p.px0 - ix_min, r0 = oyb * DOWN - p.py0 - iy_min;
+            float acc[kUfPer];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int oy = oy0 + (tid >> 6) + 4 * j;
-            if (ox < p.OW && oy < p.OH) {
-                // first tap whose up-sampled position holds a sample: (oy * DOWN + ky - py0) % UP == 0
-                const int by = oy * DOWN - p.py0, bx = ox * DOWN - p.px0;
-                const int ky0 = (UP == 1) ? 0 : (by & 1), kx0 = (UP == 1) ? 0 : (bx & 1);
-                float acc = 0.0f;
-                for (int ky = ky0; ky < p.kh; ky += UP) {
-                    const int r = ((UP == 1) ? by + ky : (by + ky) >> 1) - iy_min;
-                    for (int kx = kx0; kx < p.kw; kx += UP) {
-                        const int c = ((UP == 1) ? bx + kx : (bx + kx) >> 1) - ix_min;
-                        acc = fmaf(p.kf[ky * p.kw + kx], tile[r][c], acc);
+            for (int j = 0; j < kUfPer; ++j) acc[j] = 0.0f;
+#pragma unroll
+            for (int rr = 0; rr < (kUfPer - 1) * DOWN + KH; ++rr) {
+                float v[KW ? KW : 1];
+#pragma unroll
+                for (int kx = 0; kx < KW; ++kx) v[kx] = tile[(r0 + rr) * ts + c0 + kx];
+#pragma unroll
+                for (int j = 0; j < kUfPer; ++j) {
+                    const int ky = rr - j * DOWN;
+                    if (ky >= 0 && ky < KH) {
+#pragma unroll
+                        for (int kx = 0; kx < KW; ++kx) acc[j] = fmaf(p.kf[ky * KW + kx], v[kx], acc[j]);
                     }
                 }
-                p.y[((size_t)plane * p.OH + oy) * p.OW + ox] = acc;
+            }
+            if (ox < p.OW) {
+#pragma unroll
+                for (int j = 0; j < kUfPer; ++j)
+                    if (oyb + j < p.OH) yp[(size_t)(oyb + j) * p.OW + ox] = acc[j];
+            }
+        } else {
+            for (int j = 0; j < kUfPer; ++j) {
+                const int oy = oyb + j;
+                if (ox < p.OW && oy < p.OH) {
+                    // first tap whose up-sampled position holds a sample: (oy * DOWN + ky - py0) % UP == 0
+                    const int by = oy * DOWN - p.py0, bx = ox * DOWN - p.px0;
+                    const int ky0 = (UP == 1) ? 0 : (by & 1), kx0 = (UP == 1) ? 0 : (bx & 1);
+                    float acc = 0.0f;
+                    for (int ky = ky0; ky < kh; ky += UP) {
+                        const int r = ((UP == 1) ? by + ky : (by + ky) >> 1) - iy_min;
+                        for (int kx = kx0; kx < kw; kx += UP) {
+                            const int c = ((UP == 1) ? bx + kx : (bx + kx) >> 1) - ix_min;
+                            acc = fmaf(p.kf[ky * kw + kx], tile[r * ts + c], acc);
+                        }
+                    }
+                    yp[(size_t)oy * p.OW + ox] = acc;
+                }
             }
         }
         __syncthreads();          // the next plane restages the tile
@@ -151,12 +204,22 @@ extern "C" int enarf_upfirdn2d(const float *x, float *out, long long planes, int
     for (int i = 0; i < kUfMaxTaps * kUfMaxTaps; ++i) p.kf[i] = 0.0f;
     for (int i = 0; i < kh; ++i)
         for (int j = 0; j < kw; ++j) p.kf[i * kw + j] = kernel_host[(kh - 1 - i) * kw + (kw - 1 - j)];
-    const unsigned gx = (unsigned)((OW + kUfTW - 1) / kUfTW), gy = (unsigned)((OH + kUfTH - 1) / kUfTH);
+    // 16 outputs per thread where the tile's input is small (down = 1): twice the loads in flight per wave - the kernel is bound
+    // by the bytes it keeps in flight - at 20 KB of LDS; 8 at down = 2 (39 KB)
+    const int per = down == 2 ? 8 : 16, th = 4 * per;
+    const unsigned gx = (unsigned)((OW + kUfTW - 1) / kUfTW), gy = (unsigned)((OH + th - 1) / th);
     if (gy > 65535u) return host::fail(ENARF_ERR_UNSUPPORTED, "enarf_upfirdn2d: output height %d", OH);
     const unsigned gz = (unsigned)(planes < 65535 ? planes : 65535);
     hipStream_t st = (hipStream_t)stream;
-    if (up == 2) hipLaunchKernelGGL((upfirdn2d_kernel<2, 1>), dim3(gx, gy, gz), dim3(256), 0, st, p);
-    else if (down == 2) hipLaunchKernelGGL((upfirdn2d_kernel<1, 2>), dim3(gx, gy, gz), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((upfirdn2d_kernel<1, 1>), dim3(gx, gy, gz), dim3(256), 0, st, p);
+    // LDS tile of this configuration: the rows / columns of x that a th x 64 output tile can reach, + 1 each for an unaligned start
+    const int trows = ((th - 1) * down + kh - 1) / up + 2, tcols = ((kUfTW - 1) * down + kw - 1) / up + 2;
+    p.tstride = tcols | 1;
+    const size_t lds = (size_t)trows * p.tstride * sizeof(float);
+    const bool four = kh == 4 && kw == 4;          // the networks' [1, 3, 3, 1] filters: the unrolled sliding-column form
+    if (up == 2) hipLaunchKernelGGL((upfirdn2d_kernel<2, 1, 0, 0, 16>), dim3(gx, gy, gz), dim3(256), lds, st, p);
+    else if (down == 2 && four) hipLaunchKernelGGL((upfirdn2d_kernel<1, 2, 4, 4, 8>), dim3(gx, gy, gz), dim3(256), lds, st, p);
+    else if (down == 2) hipLaunchKernelGGL((upfirdn2d_kernel<1, 2, 0, 0, 8>), dim3(gx, gy, gz), dim3(256), lds, st, p);
+    else if (four) hipLaunchKernelGGL((upfirdn2d_kernel<1, 1, 4, 4, 16>), dim3(gx, gy, gz), dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((upfirdn2d_kernel<1, 1, 0, 0, 16>), dim3(gx, gy, gz), dim3(256), lds, st, p);
     return host::check_launch("enarf_upfirdn2d");
 }

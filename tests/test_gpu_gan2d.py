@@ -71,12 +71,13 @@ UPFIRDN_CASES = [(1, 1, (2, 1)), (1, 1, (1, 1)), (2, 1, (2, 1)), (1, 2, (2, 2)),
 
 @pytest.mark.parametrize("up,down,pad", UPFIRDN_CASES)
 @pytest.mark.parametrize("hw", [(9, 13), (64, 64), (33, 130), (128, 128)])
-def test_upfirdn2d_matches_restatement(up, down, pad, hw):
+@pytest.mark.parametrize("taps_x", [(1.0, 2.0, -1.0), (1.0, 2.0, -1.0, 0.5)])          # 4 x 3: the generic loop; 4 x 4: the unrolled one
+def test_upfirdn2d_matches_restatement(up, down, pad, hw, taps_x):
     from enarf_gan_amd.libraries.custom_stylegan2 import op
     H, W = hw
     g = torch.Generator().manual_seed(H * 1000 + W + up * 7 + down)
     x = torch.randn(2, 3, H, W, generator=g)
-    k = torch.outer(torch.tensor([1.0, 3.0, 3.0, 1.0]), torch.tensor([1.0, 2.0, -1.0])) / 7.0          # asymmetric 4 x 3
+    k = torch.outer(torch.tensor([1.0, 3.0, 3.0, 1.0]), torch.tensor(taps_x)) / 7.0          # asymmetric: a flip error would show
     want = third.upfirdn2d(x.double(), k.double(), up=up, down=down, pad=pad)
     got = op.upfirdn2d(x.cuda(), k.cuda(), up=up, down=down, pad=pad)
     assert got.shape == want.shape
