@@ -10,6 +10,7 @@
 #include "enarf_device.h"
 #include "enarf_host.h"
 #include "enarf_march.h"
+#include <type_traits>
 
 namespace enarf {
 
@@ -90,11 +91,14 @@ __global__ __launch_bounds__(256) void upfirdn2d_kernel(const UpfirParams p) {
     constexpr int NLD = (MAXR * MAXC + 255) / 256;
     const int total = nr * nc;
     const unsigned magic = (1u << 22) / (unsigned)nc + 1u;          // i / nc == (i * magic) >> 22 for i < 2^22 / nc (i < 9 400, nc <= 134)
-    for (long long plane = blockIdx.z; plane < p.planes; plane += gridDim.z) {
+    // A workgroup takes several planes (stride gridDim.z) and runs them as a two-stage pipeline: the loads of plane k + 1's
+    // tile are issued into registers BEFORE plane k is filtered out of LDS, so their latency hides behind the filter and the
+    // stores instead of being waited out once per tile (one plane per workgroup: 0.163 ms for the 128 x 128 blur).
+    // Every load of a tile is issued before the first LDS write (a load-then-store loop waits out one memory latency per
+    // row: 0.24 -> 0.40 ms when the tile grew from 35 to 67 rows); flat index over the tile, rows by multiply-shift.
+    float stage[NLD];
+    auto fetch = [&](long long plane) {
         const float *xp = p.x + (size_t)plane * p.H * p.W;
-        // every load of the tile is issued before the first LDS write (a load-then-store loop waits out one memory latency
-        // per row: 0.24 -> 0.40 ms when the tile grew from 35 to 67 rows); flat index over the tile, rows by multiply-shift
-        float stage[NLD];
 #pragma unroll
         for (int k = 0; k < NLD; ++k) {
             const int i = tid + 256 * k;
@@ -103,13 +107,21 @@ __global__ __launch_bounds__(256) void upfirdn2d_kernel(const UpfirParams p) {
             const bool in = i < total && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
             stage[k] = in ? xp[(size_t)iy * p.W + ix] : 0.0f;
         }
+    };
+    auto commit = [&]() {
 #pragma unroll
         for (int k = 0; k < NLD; ++k) {
             const int i = tid + 256 * k;
             const int r = (int)(((unsigned)i * magic) >> 22), c = i - r * nc;
             if (i < total) tile[r * ts + c] = stage[k];
         }
+    };
+    if ((long long)blockIdx.z < p.planes) fetch(blockIdx.z);
+    for (long long plane = blockIdx.z; plane < p.planes; plane += gridDim.z) {
+        commit();
         __syncthreads();
+        const bool more = plane + gridDim.z < p.planes;          // workgroup-uniform
+        if (more) fetch(plane + gridDim.z);
         float *yp = p.y + (size_t)plane * p.OH * p.OW;
         if (UP == 1 && KH > 0) {
             const int c0 = ox * DOWN - p.px0 - ix_min, r0 = oyb * DOWN - p.py0 - iy_min;
@@ -135,6 +147,38 @@ __global__ __launch_bounds__(256) void upfirdn2d_kernel(const UpfirParams p) {
                 for (int j = 0; j < kUfPer; ++j)
                     if (oyb + j < p.OH) yp[(size_t)(oyb + j) * p.OW + ox] = acc[j];
             }
+        } else if (UP == 2 && DOWN == 1 && KH == 4 && KW == 4) {
+            // the 2x up-sampler: an output sees 2 x 2 of the 4 x 4 taps (those whose zero-stuffed position holds a sample).
+            // Which columns: by the parity of the thread's ox (taps picked once by 8 selects); which rows: by the parity of the
+            // output row, which alternates down the column from a wave-uniform start - so the 16 outputs of a thread read 10
+            // LDS rows x 2 columns once and share them.
+            const int bx = ox - p.px0, kx0 = bx & 1, cA = ((bx + kx0) >> 1) - ix_min;
+            const int by0 = oyb - p.py0, par = by0 & 1, r0 = ((by0 + par) >> 1) - iy_min;
+            float w[4][2];
+#pragma unroll
+            for (int ky = 0; ky < 4; ++ky) {
+                w[ky][0] = kx0 ? p.kf[ky * 4 + 1] : p.kf[ky * 4 + 0];
+                w[ky][1] = kx0 ? p.kf[ky * 4 + 3] : p.kf[ky * 4 + 2];
+            }
+            constexpr int NROW = kUfPer / 2 + 2;
+            float v[NROW][2];
+#pragma unroll
+            for (int r = 0; r < NROW; ++r) { v[r][0] = tile[(r0 + r) * ts + cA]; v[r][1] = tile[(r0 + r) * ts + cA + 1]; }
+            float acc[kUfPer];
+            auto column = [&](auto PAR) {          // PAR = parity of the first output row's position (wave-uniform)
+#pragma unroll
+                for (int j = 0; j < kUfPer; ++j) {
+                    constexpr int P = decltype(PAR)::value;
+                    const int ky0 = (P + j) & 1, ro = (j + P + ky0) / 2 - P;      // row of the first tap, relative to r0
+                    acc[j] = w[ky0][0] * v[ro][0] + w[ky0][1] * v[ro][1] + w[ky0 + 2][0] * v[ro + 1][0] + w[ky0 + 2][1] * v[ro + 1][1];
+                }
+            };
+            if (par) column(std::integral_constant<int, 1>{}); else column(std::integral_constant<int, 0>{});
+            if (ox < p.OW) {
+#pragma unroll
+                for (int j = 0; j < kUfPer; ++j)
+                    if (oyb + j < p.OH) yp[(size_t)(oyb + j) * p.OW + ox] = acc[j];
+            }
         } else {
             for (int j = 0; j < kUfPer; ++j) {
                 const int oy = oyb + j;
@@ -154,7 +198,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_kernel(const UpfirParams p) {
                 }
             }
         }
-        __syncthreads();          // the next plane restages the tile
+        __syncthreads();          // the next plane's tile replaces this one
     }
 }
 
@@ -209,14 +253,19 @@ extern "C" int enarf_upfirdn2d(const float *x, float *out, long long planes, int
     const int per = down == 2 ? 8 : 16, th = 4 * per;
     const unsigned gx = (unsigned)((OW + kUfTW - 1) / kUfTW), gy = (unsigned)((OH + th - 1) / th);
     if (gy > 65535u) return host::fail(ENARF_ERR_UNSUPPORTED, "enarf_upfirdn2d: output height %d", OH);
-    const unsigned gz = (unsigned)(planes < 65535 ? planes : 65535);
+    // planes per workgroup: enough workgroups for two rounds of 8 per CU, the rest of the planes in each one's pipeline (<= 8)
+    long long ppw = planes * gx * gy / ((long long)(device_cus() > 0 ? device_cus() : 256) * 16);
+    ppw = ppw < 1 ? 1 : (ppw > 8 ? 8 : ppw);
+    long long gzl = (planes + ppw - 1) / ppw;
+    const unsigned gz = (unsigned)(gzl < 65535 ? gzl : 65535);
     hipStream_t st = (hipStream_t)stream;
     // LDS tile of this configuration: the rows / columns of x that a th x 64 output tile can reach, + 1 each for an unaligned start
     const int trows = ((th - 1) * down + kh - 1) / up + 2, tcols = ((kUfTW - 1) * down + kw - 1) / up + 2;
     p.tstride = tcols | 1;
     const size_t lds = (size_t)trows * p.tstride * sizeof(float);
     const bool four = kh == 4 && kw == 4;          // the networks' [1, 3, 3, 1] filters: the unrolled sliding-column form
-    if (up == 2) hipLaunchKernelGGL((upfirdn2d_kernel<2, 1, 0, 0, 16>), dim3(gx, gy, gz), dim3(256), lds, st, p);
+    if (up == 2 && four) hipLaunchKernelGGL((upfirdn2d_kernel<2, 1, 4, 4, 16>), dim3(gx, gy, gz), dim3(256), lds, st, p);
+    else if (up == 2) hipLaunchKernelGGL((upfirdn2d_kernel<2, 1, 0, 0, 16>), dim3(gx, gy, gz), dim3(256), lds, st, p);
     else if (down == 2 && four) hipLaunchKernelGGL((upfirdn2d_kernel<1, 2, 4, 4, 8>), dim3(gx, gy, gz), dim3(256), lds, st, p);
     else if (down == 2) hipLaunchKernelGGL((upfirdn2d_kernel<1, 2, 0, 0, 8>), dim3(gx, gy, gz), dim3(256), lds, st, p);
     else if (four) hipLaunchKernelGGL((upfirdn2d_kernel<1, 1, 4, 4, 16>), dim3(gx, gy, gz), dim3(256), lds, st, p);
