@@ -133,3 +133,28 @@ def test_two_rank_accumulated_async_gradient_exchange():
     port = 33500 + (os.getpid() % 2000)
     mp.spawn(_accum_worker, args=(2, port, ret), nprocs=2, join=True)
     assert ret["ok"], dict(ret)
+
+
+def _stddev_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from enarf_gan_amd.libraries.custom_stylegan2.net import minibatch_stddev
+    feats = [torch.randn(8, 6, 4, 4, generator=torch.Generator().manual_seed(10 + r)) for r in range(world)]
+    out = minibatch_stddev(feats[rank], 4, ddp=True, world_size=world)           # the discriminator's ddp branch (net.py:665-667)
+    if rank == 0:
+        local = [minibatch_stddev(f, 4)[:, 6] for f in feats]                   # every rank's own statistic
+        want = sum(local) / world
+        ret["ok"] = bool(torch.allclose(out[:, 6], want, rtol=1e-6, atol=1e-7) and torch.equal(out[:, :6], feats[0]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_minibatch_stddev_is_averaged_over_the_ranks():
+    """the only collective inside the discriminator: the stddev statistic is all-reduced and divided by world_size"""
+    mgr = mp.get_context("spawn").Manager()
+    ret = mgr.dict()
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_stddev_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert ret["ok"]
