@@ -224,3 +224,34 @@ def test_one_gan_step_through_renderer_background_and_discriminator():
     for n_, p in dis.named_parameters():
         assert p.grad is not None and bool(torch.isfinite(p.grad).all()), n_
     assert float(dis.convs[1].conv2[1].weight.grad.abs().max()) > 0
+
+
+def test_gan_iteration_tool_runs_and_reports():
+    """tools/bench_gan_step.py (BASELINE configs[2] in small): two timed iterations of generator + discriminator + R1 with two
+    micro-batches, in a process of its own; the line it prints carries the phases and a finite image statistic"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "bench_gan_step.py"), "--size", "32", "--batch", "4", "--accum", "2",
+                        "--nc", "16", "--nf", "16", "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["unit"] == "it/s" and line["value"] > 0 and line["n_gpus"] == 1
+    assert set(line["phases_ms_mean_rank0"]) == {"generator forward + backward (+ exchange)", "discriminator step", "R1 step"}
+    assert 0 < line["fake_image_abs_mean"] < 10
+
+
+def test_mask_regularisers_match_their_formulas():
+    from enarf_gan_amd.models.loss import nerf_bone_loss, nerf_patch_loss, push_to_background
+    g = torch.Generator().manual_seed(0)
+    mask = torch.rand(2, 16, 16, generator=g).cuda()
+    bone = (torch.rand(2, 32, 32, generator=g) > 0.9).float().cuda()
+    k = int(mask.numel() * 0.3)
+    want_bg = mask.flatten().sort()[0][:k].square().mean()
+    torch.testing.assert_close(push_to_background(mask, 0.3), want_bg)
+    assert push_to_background(mask, 0.0) == 0
+    pooled = F.max_pool2d(bone[:, None], 2, 2)[:, 0] > 0.5
+    want_bone = ((1 - mask).square() * pooled).sum() / pooled.sum()
+    torch.testing.assert_close(nerf_bone_loss(mask, bone), want_bone)
+    torch.testing.assert_close(nerf_patch_loss(mask, bone, 0.3, coef=10), (want_bg + want_bone) * 10)
