@@ -38,6 +38,8 @@ def _bias_act_call(x: torch.Tensor, bias, ref, slope: float, gain: float) -> tor
             raise ValueError(f"fused_leaky_relu: bias has {b.numel()} entries, input has {Cn} channels")
     r = None if ref is None else _dev_f32(ref, "ref")
     out = torch.empty_like(x)
+    if x.numel() == 0:                     # an empty batch has no storage to point at
+        return out
     _lib.check(lib.enarf_bias_act(_p(x), _p(b), _p(r), _p(out), outer, Cn, inner, float(slope), float(gain), _stream(x.device)),
                "enarf_bias_act")
     return out
@@ -125,6 +127,8 @@ def _upfirdn_call(x: torch.Tensor, filt: Tuple[float, ...], kh: int, kw: int, up
     if OH <= 0 or OW <= 0:
         raise ValueError(f"upfirdn2d: empty output for input {H}x{W}, filter {kh}x{kw}, up {up}, down {down}, pad {pads}")
     out = torch.empty(N, Cn, OH, OW, dtype=torch.float32, device=x.device)
+    if out.numel() == 0:
+        return out
     karr = (C.c_float * (kh * kw))(*filt)
     _lib.check(lib.enarf_upfirdn2d(_p(x), _p(out), N * Cn, H, W, karr, kh, kw, up, down, px0, px1, py0, py1, _stream(x.device)),
                "enarf_upfirdn2d")

@@ -255,3 +255,32 @@ def test_mask_regularisers_match_their_formulas():
     want_bone = ((1 - mask).square() * pooled).sum() / pooled.sum()
     torch.testing.assert_close(nerf_bone_loss(mask, bone), want_bone)
     torch.testing.assert_close(nerf_patch_loss(mask, bone, 0.3, coef=10), (want_bg + want_bone) * 10)
+
+
+def test_ops_edge_cases():
+    """empty batches, maps smaller than the filter, a single pixel, and arguments the library refuses"""
+    from enarf_gan_amd.libraries.custom_stylegan2 import op
+    k = op.make_kernel([1, 3, 3, 1]).cuda()
+    # a 1 x 1 and a 2 x 3 map under the blur (padding makes room for the 4 x 4 filter)
+    for h, w in ((1, 1), (2, 3), (5, 1)):
+        x = torch.randn(3, 2, h, w, generator=torch.Generator().manual_seed(h * 10 + w))
+        for kw in (dict(pad=(2, 1)), dict(up=2, pad=(2, 1)), dict(down=2, pad=(2, 2))):
+            want = third.upfirdn2d(x, k.cpu() * (4 if "up" in kw else 1), **kw)
+            got = op.upfirdn2d(x.cuda(), k * (4 if "up" in kw else 1), **kw)
+            assert got.shape == want.shape and _rel(got, want) < 2e-6, (h, w, kw)
+    # no room for the filter: an error, as an empty convolution output would be
+    with pytest.raises(ValueError):
+        op.upfirdn2d(torch.zeros(1, 1, 2, 2, device="cuda"), k, pad=(0, 0))
+    # empty batch: nothing launched, shapes kept
+    e = op.upfirdn2d(torch.zeros(0, 4, 8, 8, device="cuda"), k, pad=(2, 1))
+    assert e.shape == (0, 4, 8, 8)
+    assert op.fused_leaky_relu(torch.zeros(0, 4, 8, 8, device="cuda"), torch.zeros(4, device="cuda")).shape == (0, 4, 8, 8)
+    # a 9-tap filter and a bias of the wrong length are refused, with a message
+    with pytest.raises(NotImplementedError, match="filter"):          # ENARF_ERR_UNSUPPORTED
+        op.upfirdn2d(torch.zeros(1, 1, 16, 16, device="cuda"), torch.ones(9, 9, device="cuda"), pad=(4, 4))
+    with pytest.raises(ValueError, match="bias"):
+        op.fused_leaky_relu(torch.zeros(2, 4, 3, 3, device="cuda"), torch.zeros(5, device="cuda"))
+    # a 1-D filter is the separable outer product, as make_kernel builds it
+    y = torch.randn(1, 2, 12, 12, device="cuda")
+    torch.testing.assert_close(op.upfirdn2d(y, torch.tensor([1.0, 3.0, 3.0, 1.0], device="cuda") / 8, pad=(2, 1)),
+                               op.upfirdn2d(y, k, pad=(2, 1)))
