@@ -159,14 +159,18 @@ class _UpFirDn2d(torch.autograd.Function):
         return gx, None, None, None, None, None, None
 
 
-def upfirdn2d(input: torch.Tensor, kernel: torch.Tensor, up: int = 1, down: int = 1, pad: Sequence[int] = (0, 0)) -> torch.Tensor:
-    """input (N, C, H, W); kernel (kh, kw); pad = (pad0, pad1) for both axes or (x0, x1, y0, y1)."""
+def upfirdn2d(input: torch.Tensor, kernel: torch.Tensor, up: int = 1, down: int = 1, pad: Sequence[int] = (0, 0),
+              gain: float = 1.0) -> torch.Tensor:
+    """input (N, C, H, W); kernel (kh, kw); pad = (pad0, pad1) for both axes or (x0, x1, y0, y1); `gain` scales the filter
+    (on the host copy: `kernel * 4` would be a new tensor, and a device-to-host copy, on every call)."""
     pads = tuple(int(p) for p in pad)
     if len(pads) == 2:
         pads = (pads[0], pads[1], pads[0], pads[1])
     if len(pads) != 4:
         raise ValueError(f"upfirdn2d: pad {pad} must have 2 or 4 entries")
     filt, kh, kw = _host_filter(kernel)
+    if gain != 1.0:
+        filt = tuple(v * float(gain) for v in filt)
     return _UpFirDn2d.apply(input, filt, kh, kw, int(up), int(down), pads)
 
 

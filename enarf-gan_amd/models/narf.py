@@ -117,16 +117,22 @@ class TriPlaneNARF(nn.Module):
             self.tri_plane = nn.Parameter(torch.zeros(1, self.num_bone * 3, 256, 256) / self.trimask_lr_mul)
         # producer precedence as in models/narf.py:29-71: constant_triplane, constant_trimask, deformation_field, StyleGAN
         self.uses_warp = bool(config.deformation_field) and not config.constant_triplane and not self.constant_trimask
-        self.flow_generator = None         # deformation_field: assign a callable (z, encoded_length, ...) -> flow (B, 6, 256, 256)
-        self.generator = None              # constant_trimask: assign a callable (z, encoded_length, ...) -> (B, 96, 256, 256)
+        # The StyleGAN2-ADA networks behind the producers (models/narf.py:31, :41, :71: prepare_stylegan2) are this repo's
+        # restatement on the HIP ops (libraries/stylegan2_ada/networks.py), registered under the reference's attribute names so
+        # that a snapshot's `tri_plane_gen.*` / `generator.*` / `flow_generator.*` keys load. Any of the three can be replaced
+        # by a plain callable (z, encoded_length, truncation_psi=...) -> planes: see __setattr__.
+        self.flow_generator = None         # deformation_field: (z, encoded_length, ...) -> flow (B, 6, 256, 256)
+        self.generator = None              # constant_trimask: (z, encoded_length, ...) -> (B, 96, 256, 256)
         if config.constant_triplane:
             self.tri_plane_gen = lambda z, *args, **kwargs: self.tri_plane.expand(z.shape[0], -1, -1, -1)
         elif self.constant_trimask:
+            self.generator = self.prepare_stylegan2(self.feat_dim * 3)
             self.tri_plane_gen = self._trimask_tri_plane    # models/narf.py:32-38
         elif self.uses_warp:
+            self.flow_generator = self.prepare_stylegan2(2 * 3)
             self.tri_plane_gen = self._warped_tri_plane     # models/narf.py:40-58 with the HIP warp producer
         else:
-            self.tri_plane_gen = None      # the StyleGAN2-ADA producer is out of scope: assign a callable
+            self.tri_plane_gen = self.prepare_stylegan2((self.feat_dim + self.num_bone) * 3)      # models/narf.py:71
         self.mlp = StyledMLP(32, 64, 4, style_dim=self.z2_dim)
         self._cl_cache = None              # (data_ptr, _version, shape) -> channel-last copy of a constant tri-plane
 
@@ -166,15 +172,31 @@ class TriPlaneNARF(nn.Module):
         return transform_pose(pose_to_camera, bone_length, self.origin_location, self.parent_id)
 
     # ---- tri-plane handling ---------------------------------------------------------------------------------------
+    _PRODUCERS = ("tri_plane_gen", "generator", "flow_generator")
+
+    def __setattr__(self, name, value):
+        """The three producer slots hold a network (registered: its parameters train and load with the model) or ANY callable
+        with the producer's signature - e.g. a cached tri-plane, or another synthesis network; torch refuses a plain function
+        where a child module is registered, so the slot is cleared first."""
+        if name in self._PRODUCERS and not isinstance(value, nn.Module):
+            self.__dict__.get("_modules", {}).pop(name, None)
+            object.__setattr__(self, name, value)
+            return
+        if name in self._PRODUCERS:
+            self.__dict__.pop(name, None)
+        super().__setattr__(name, value)
+
+    def prepare_stylegan2(self, out_channels):
+        """models/narf.py:80-83: z -> planes, conditioned on the encoded bone lengths"""
+        from ..libraries.stylegan2_ada.networks import prepare_triplane_generator
+        return prepare_triplane_generator(self.z_dim, self.w_dim, out_channels, self.num_frequency_for_other * 2 * self.num_bone)
+
     def encode_bone_length(self, bone_length: torch.Tensor) -> torch.Tensor:
         """(B, P, 1) part bone lengths -> (B, P * 2F) conditioning vector of the tri-plane producers
         (models/narf.py:286-288: multi_part_positional_encoding(bone_length, num_frequency_for_other, num_bone)[:, :, 0])."""
         return multi_part_positional_encoding(bone_length, self.num_frequency_for_other, num_bone=self.num_bone)[:, :, 0]
 
     def compute_tri_plane_feature(self, z, bone_length, truncation_psi=1):
-        if self.tri_plane_gen is None:
-            raise NotImplementedError("the StyleGAN2-ADA tri-plane generator is out of scope (SURVEY.md §2): assign "
-                                      "model.tri_plane_gen or pass model_input['tri_plane_feature']")
         if self.config.constant_triplane:
             bs = bone_length.shape[0] if z is None else z.shape[0]
             return self.tri_plane.expand(bs, -1, -1, -1)
@@ -182,9 +204,6 @@ class TriPlaneNARF(nn.Module):
 
     # ---- constant_trimask producer (models/narf.py:32-38) -------------------------------------------------------------
     def _feature_planes(self, z, *args, **kwargs) -> torch.Tensor:
-        if self.generator is None:
-            raise NotImplementedError("constant_trimask: the StyleGAN2-ADA feature-plane generator is out of scope (SURVEY.md "
-                                      "§2): assign model.generator, a callable (z, encoded_length, ...) -> (B, 96, 256, 256)")
         return self.generator(z, *args, **kwargs)
 
     def _trimask_tri_plane(self, z, *args, **kwargs) -> torch.Tensor:
@@ -194,9 +213,6 @@ class TriPlaneNARF(nn.Module):
 
     # ---- deformation-field producer (models/narf.py:40-58) ----------------------------------------------------------
     def _flow(self, z, *args, **kwargs) -> torch.Tensor:
-        if self.flow_generator is None:
-            raise NotImplementedError("deformation_field: the StyleGAN2 flow generator is out of scope (SURVEY.md §2): "
-                                      "assign model.flow_generator, a callable (z, ...) -> flow (B, 6, 256, 256)")
         return self.flow_generator(z, *args, **kwargs)
 
     def _constant_planes_cl(self) -> torch.Tensor:

@@ -187,3 +187,46 @@ def test_random_window_is_an_integer_crop():
     for b in range(2):
         x0 = int(out[b, 0, 0, 0] - img[b, 0, 0, 0])
         assert 0 <= x0 <= 6 and torch.equal(out[b], img[b, :, :, x0:x0 + 6])
+
+
+# ------------------------------------------------------------------------------------------ tri-plane producer (8f rank 2)
+def test_triplane_generator_structure():
+    """prepare_triplane_generator (libraries/triplane/triplane_nerf.py:17-29): 256 x 256 planes, widths min(32768 / res, 512),
+    8 mapping layers with the bone-length embedding, 14 style vectors, the published module names"""
+    from enarf_gan_amd.libraries.stylegan2_ada.networks import prepare_triplane_generator
+    g = prepare_triplane_generator(512, 512, (32 + 23) * 3, c_dim=23 * 8)
+    assert g.num_ws == 14 and g.synthesis.block_resolutions == [4, 8, 16, 32, 64, 128, 256]
+    sd = g.state_dict()
+    assert sd["synthesis.b4.const"].shape == (512, 4, 4)
+    assert sd["synthesis.b64.conv1.weight"].shape == (512, 512, 3, 3)
+    assert sd["synthesis.b128.conv0.weight"].shape == (256, 512, 3, 3) and sd["synthesis.b256.conv0.weight"].shape == (128, 256, 3, 3)
+    assert sd["synthesis.b256.torgb.weight"].shape == (165, 128, 1, 1) and sd["synthesis.b256.torgb.affine.weight"].shape == (128, 512)
+    assert sd["mapping.embed.weight"].shape == (512, 184) and sd["mapping.fc0.weight"].shape == (512, 1024)
+    assert sd["mapping.fc7.weight"].shape == (512, 512) and sd["mapping.w_avg"].shape == (512,)
+    assert not any("noise" in k for k in sd)                                     # use_noise=False
+    assert "synthesis.b4.conv0.weight" not in sd and "synthesis.b8.conv0.resample_filter" in sd
+    torch.testing.assert_close(sd["synthesis.b8.resample_filter"], third.make_kernel([1, 3, 3, 1]))
+    # affine biases start at 1, mapping weights are stored divided by the learning-rate multiplier 0.01
+    assert float(sd["synthesis.b8.conv0.affine.bias"].min()) == 1.0 and 50 < float(sd["mapping.fc3.weight"].std()) < 200
+
+
+def test_model_builds_the_reference_producers_and_accepts_callables():
+    from test_host_cpu import _nerf_cfg
+    from enarf_gan_amd import synth
+    from enarf_gan_amd.libraries.stylegan2_ada.networks import Generator
+    from enarf_gan_amd.models.narf import TriPlaneNARF
+    parents = synth.SMPL_PARENTS if hasattr(synth, "SMPL_PARENTS") else synth.make_scene(8, 1, "center_fixed", 4)["parents"]
+    m = TriPlaneNARF(_nerf_cfg(constant_triplane=False), [64, 32], 24, parent=parents, num_bone_param=23)
+    assert isinstance(m.tri_plane_gen, Generator) and m.tri_plane_gen.img_channels == (32 + 23) * 3 and m.tri_plane_gen.c_dim == 23 * 8
+    assert "tri_plane_gen.synthesis.b4.const" in m.state_dict() and m.generator is None and m.flow_generator is None
+    m.tri_plane_gen = lambda z, enc, truncation_psi=1: torch.zeros(z.shape[0], 165, 256, 256)       # any callable takes the slot
+    assert not any(k.startswith("tri_plane_gen.") for k in m.state_dict())
+    assert m.compute_tri_plane_feature(torch.zeros(2, 64), torch.ones(2, 23, 1)).shape == (2, 165, 256, 256)
+    m.tri_plane_gen = Generator(64, 184, 512, 256, 165)                                             # ... and a network again
+    assert "tri_plane_gen.mapping.w_avg" in m.state_dict()
+    t = TriPlaneNARF(_nerf_cfg(constant_triplane=False, constant_trimask=True), [64, 32], 24, parent=parents, num_bone_param=23)
+    assert isinstance(t.generator, Generator) and t.generator.img_channels == 96 and "generator.synthesis.b256.torgb.bias" in t.state_dict()
+    f = TriPlaneNARF(_nerf_cfg(constant_triplane=False, deformation_field=True), [64, 32], 24, parent=parents, num_bone_param=23)
+    assert isinstance(f.flow_generator, Generator) and f.flow_generator.img_channels == 6
+    c = TriPlaneNARF(_nerf_cfg(), [64, 32], 24, parent=parents, num_bone_param=23)
+    assert not any(k.startswith(("tri_plane_gen.", "generator.", "flow_generator.")) for k in c.state_dict())

@@ -4,9 +4,9 @@
 + StyleGAN2 background network, residual discriminator, non-saturating loss + bone-guided mask loss, Adam(0, 0.99), R1 every
 16th iteration. NOT the headline metric (bench.py is): this times the loop the renderer is invoked in.
 
-The tri-plane synthesis network is an un-vendored submodule of the reference; one learnable tri-plane per frame stands in for
-its output ("GAN-style tri-plane per image"), so the renderer's backward runs in full and its tri-plane
-gradient ends where the synthesis network's backward would start. Data-parallel over WORLD_SIZE ranks as the reference's
+The tri-planes come from the generator's own StyleGAN2-ADA synthesis network (libraries/stylegan2_ada/networks.py: this repo's
+restatement of the un-vendored submodule); `--producer planes` replaces it by one learnable tri-plane per frame (SURVEY.md 8d,
+C2: "GAN-style tri-plane per image"), which isolates the renderer's share. Data-parallel over WORLD_SIZE ranks as the reference's
 DistributedDataParallel: the batch is dealt to the ranks, every micro-batch's generator gradients are all-reduced in buckets
 while the next micro-batch runs (sharding.GradientReducer), the discriminator's after its backward.
   python tools/bench_gan_step.py [--batch 32 --accum 2 --size 128 --steps 6 --warmup 2]
@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--r1-every", type=int, default=16)
+    ap.add_argument("--producer", choices=("stylegan", "planes"), default="stylegan")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo for a rehearsal)")
     args = ap.parse_args()
     world, rank, local = int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0))
@@ -84,6 +85,8 @@ def main():
     mb = frames // args.accum
     torch.manual_seed(1234 + rank)
     gen, dis, tri, data = build(args, dev, frames)
+    if args.producer == "planes":
+        gen.nerf.tri_plane_gen = None          # drops the synthesis network's parameters from the generator
     gen_params = [p for p in gen.parameters() if p.requires_grad]
     dis_params = list(dis.parameters())
     lr_scale = args.batch / 32
@@ -92,14 +95,20 @@ def main():
     g_red = sharding.GradientReducer(gen_params, world) if dist is not None else None
     d_red = sharding.GradientReducer(dis_params, world) if dist is not None else None
     ev = {}
+    t_w = time.perf_counter()
 
     def mark(name, it):
         e = torch.cuda.Event(enable_timing=True)
         e.record()
         ev.setdefault(it, []).append((name, e))
 
-    def iteration(it, timed=False):
+    def iteration(it, timed=False, talk=False):
         m = (lambda n: mark(n, it)) if timed else (lambda n: None)
+
+        def say(what):          # the first iteration takes minutes (library warm-up): keep the log moving
+            if talk and rank == 0:
+                torch.cuda.synchronize()
+                print(f"  [{time.perf_counter() - t_w:6.1f} s] {what}", file=sys.stderr, flush=True)
         m("start")
         # ---- generator step (train_ENARF_GAN.py:108-128)
         dis.requires_grad_(False)
@@ -107,13 +116,16 @@ def main():
 
         def backward_of(k):
             sl = slice(k * mb, (k + 1) * mb)
-            gen.nerf.tri_plane_gen = lambda z, enc, truncation_psi=1: tri[sl]
+            if args.producer == "planes":
+                gen.nerf.tri_plane_gen = lambda z, enc, truncation_psi=1: tri[sl]
             z = torch.randn(mb, 4 * 256, device=dev)
             fake, mask, _, _ = gen(data["pose_to_camera"][sl], None, data["bone_length"][sl], z, data["inv_intrinsics"][sl])
             loss = adv_loss_gen(dis(fake, dist is not None, world), "ce") + nerf_patch_loss(mask, data["bone_mask"][sl], gen.background_ratio)
-            grads = torch.autograd.grad(loss, gen_params + [tri], allow_unused=True)
-            tri.grad = grads[-1] if (k == 0 or tri.grad is None) else tri.grad + grads[-1]
+            grads = torch.autograd.grad(loss, gen_params + [tri], allow_unused=True)       # tri: unused with the real producer
+            if grads[-1] is not None:
+                tri.grad = grads[-1] if (k == 0 or tri.grad is None) else tri.grad + grads[-1]
             fakes.append(fake.detach())
+            say(f"generator micro-batch {k}")
             return list(grads[:-1])
         tri.grad = None
         sharding.accumulate_and_reduce(range(args.accum), backward_of, gen_params, g_red)
@@ -126,6 +138,7 @@ def main():
         loss_d = adv_loss_dis(dis(real, dist is not None, world), dis(fake, dist is not None, world), "ce")
         sharding.accumulate_and_reduce([0], lambda _: list(torch.autograd.grad(loss_d, dis_params)), dis_params, d_red)
         dis_opt.step()
+        say("discriminator step")
         m("discriminator step")
         if args.r1_every and it % args.r1_every == 0:      # :149-165
             x = real.detach().requires_grad_(True)
@@ -142,7 +155,7 @@ def main():
         torch.cuda.synchronize()
 
     t_w = time.perf_counter()
-    iteration(0)                       # untimed: every phase once, R1 included (the convolution library picks its algorithms
+    iteration(0, talk=True)            # untimed: every phase once, R1 included (the convolution library picks its algorithms
     barrier()                          # on first use of a shape: minutes on a fresh box)
     if rank == 0:
         print(f"first iteration (library warm-up): {time.perf_counter() - t_w:.1f} s", file=sys.stderr, flush=True)
@@ -169,12 +182,12 @@ def main():
             "value": args.steps / elapsed, "unit": "it/s", "frames_per_s": args.batch * args.steps / elapsed,
             "ms_per_iteration": elapsed / args.steps * 1e3, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "config": {"workload": f"{args.size}x{args.size}, batch {args.batch} = {world} rank(s) x {args.accum} micro-batch(es) x {mb} frames, "
-                                   f"Nc {args.nc} + Nf {args.nf}, one learnable tri-plane per frame in place of the un-vendored synthesis network, "
+                                   f"Nc {args.nc} + Nf {args.nf}, tri-planes from " + ("the StyleGAN2-ADA synthesis network, " if args.producer == "stylegan" else "one learnable tri-plane per frame, ") +
                                    f"R1 on {n_r1} of {args.steps} iterations", "backend": (args.backend or "nccl") if world > 1 else None},
             "dtype": "f32 (renderer MLP products as 3-term split fp16)", "data": "synthetic",
             "phases_ms_mean_rank0": {k: sum(v) / len(v) for k, v in phases.items()},
             "fake_image_abs_mean": float(out.abs().mean()),
-            "params_M": {"generator (renderer MLP + background network)": sum(p.numel() for p in gen_params) / 1e6,
+            "params_M": {"generator (renderer MLP + background network" + (" + tri-plane synthesis network)" if args.producer == "stylegan" else ")"): sum(p.numel() for p in gen_params) / 1e6,
                          "discriminator": sum(p.numel() for p in dis_params) / 1e6}}))
     if dist is not None:
         dist.destroy_process_group()
