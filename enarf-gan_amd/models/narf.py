@@ -5,9 +5,10 @@ State-dict keys on the path: `tri_plane`, `mlp.layers.{0,1,2}.{b
 conv.modulation.weight, conv.modulation.bias, noise.weight}`, buffers `canonical_pose`,
 `canonical_bone_length`, `canonical_joints`, `canonical_parent_joints` - so reference snapshots load.
 
-Out of scope here: the StyleGAN2-ADA synthesis networks themselves (un-vendored in the reference).
-They plug in as callables with the reference's calling convention `net(z, encoded_length, truncation_psi=...)`, where
-`encoded_length` (B, P * 2 * num_frequency_for_other) is the bone-length positional encoding of models/narf.py:277-290:
+The StyleGAN2-ADA synthesis networks behind the producers (un-vendored in the reference) are this repo's restatement
+(libraries/stylegan2_ada/networks.py), built and registered as the reference does (models/narf.py:31, :41, :71); any other
+callable with the calling convention `net(z, encoded_length, truncation_psi=...)` can take a slot, where `encoded_length`
+(B, P * 2 * num_frequency_for_other) is the bone-length positional encoding of models/narf.py:277-290:
   * default (GAN):        `model.tri_plane_gen` -> (B, (32 + P) * 3, 256, 256)
   * `constant_trimask`:   `model.generator`     -> (B, 96, 256, 256) feature planes; the part-probability planes are the
                           learned constant `model.tri_plane` (1, 3P, 256, 256) x `constant_trimask_lr_mul` (narf.py:32-38)
