@@ -4,10 +4,10 @@ pose / camera caches. Readers execute nothing from the file.
 * snapshots - `torch.save({"iteration", "start_time", "gen", "dis", "gen_opt", "dis_opt"})` (train_ENARF_GAN.py:278-294;
   train_DSO.py:287-298); demos load `["gen"]` with `strict=False` (DSO_demo.py:37-42, ENARF_GAN_demo.py). The mirror
   generators keep the reference's state-dict keys (`nerf.tri_plane`, `nerf.mlp.layers.{0,1,2}.*`, the canonical-pose
-  buffers; `background_generator.*` with libraries/custom_stylegan2/net.py's), so a reference snapshot's weights load by
-  name; what belongs to a network this repo does not build (the StyleGAN2-ADA tri-plane synthesis network: an un-vendored
-  submodule of the reference) is reported, not loaded. `["dis"]` loads into libraries.custom_stylegan2.net.Discriminator
-  with a plain `load_state_dict`. Read with `torch.load(weights_only=True)`.
+  buffers; `background_generator.*` with libraries/custom_stylegan2/net.py's; `nerf.tri_plane_gen.*` with
+  libraries/stylegan2_ada/networks.py's), so a reference snapshot's weights load by name; a key with no counterpart or another
+  shape is reported, not loaded. `["dis"]` loads into libraries.custom_stylegan2.net.Discriminator with a plain
+  `load_state_dict`. Read with `torch.load(weights_only=True)`.
 * `cache.pickle` (dataset/dataset.py:152-185; README.md:40-48) - {"img": [blosc-packed uint8 (3, S, S)], "camera_intrinsic"
   (N, 3, 3), "smpl_pose" (N, 24, 4, 4) [, "camera_rotation" (N, 3, 3), "camera_translation" (N, 3, 1), "frame_id" (N,)]}.
 * `sample_data.pickle` (data_preprocess/ZJU/prepare_sample_data.py:59-66) - [{"pose_3d" (24, 4, 4), "intrinsics" (3, 3),
