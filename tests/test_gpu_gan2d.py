@@ -400,3 +400,19 @@ def test_gan_generator_end_to_end_with_its_own_producer():
         gr = dict(gen.named_parameters())[name].grad
         assert gr is not None and bool(torch.isfinite(gr).all()), name
     assert float(dict(gen.named_parameters())["nerf.tri_plane_gen.synthesis.b256.torgb.weight"].grad.abs().max()) > 0
+
+
+def test_discriminator_runs_under_bf16_autocast():
+    """an opt-in the reference does not have: torch.autocast around the 2-D networks. The library convolutions run in bf16, the HIP
+    ops take whatever arrives and compute in fp32; outputs and gradients stay close to the fp32 run"""
+    from enarf_gan_amd.libraries.custom_stylegan2 import net
+    dis = net.Discriminator(SimpleNamespace(minibatch_std=True), size=32)
+    third.fill_by_name(dis)
+    dis = dis.cuda()
+    x = torch.randn(4, 3, 32, 32, device="cuda", generator=torch.Generator(device="cuda").manual_seed(0)).requires_grad_(True)
+    ref = dis(x)
+    (g_ref,) = torch.autograd.grad(ref.sum(), x)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        out = dis(x)
+    (g_amp,) = torch.autograd.grad(out.float().sum(), x)
+    assert bool(torch.isfinite(out).all()) and _rel(out.float(), ref) < 5e-2 and _rel(g_amp, g_ref) < 1e-1
