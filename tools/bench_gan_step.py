@@ -69,6 +69,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--r1-every", type=int, default=16)
     ap.add_argument("--producer", choices=("stylegan", "planes"), default="stylegan")
+    ap.add_argument("--amp", action="store_true", help="opt-in, not the reference's arithmetic: torch.autocast(bf16) around the 2-D "
+                    "networks' library convolutions (the HIP renderer and the HIP ops compute in fp32 either way)")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo for a rehearsal)")
     args = ap.parse_args()
     world, rank, local = int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0))
@@ -96,6 +98,8 @@ def main():
     d_red = sharding.GradientReducer(dis_params, world) if dist is not None else None
     ev = {}
     t_w = time.perf_counter()
+    import contextlib
+    amp = (lambda: torch.autocast("cuda", dtype=torch.bfloat16)) if args.amp else contextlib.nullcontext
 
     def mark(name, it):
         e = torch.cuda.Event(enable_timing=True)
@@ -119,8 +123,11 @@ def main():
             if args.producer == "planes":
                 gen.nerf.tri_plane_gen = lambda z, enc, truncation_psi=1: tri[sl]
             z = torch.randn(mb, 4 * 256, device=dev)
-            fake, mask, _, _ = gen(data["pose_to_camera"][sl], None, data["bone_length"][sl], z, data["inv_intrinsics"][sl])
-            loss = adv_loss_gen(dis(fake, dist is not None, world), "ce") + nerf_patch_loss(mask, data["bone_mask"][sl], gen.background_ratio)
+            with amp():
+                fake, mask, _, _ = gen(data["pose_to_camera"][sl], None, data["bone_length"][sl], z, data["inv_intrinsics"][sl])
+                fake, mask = fake.float(), mask.float()
+                logits = dis(fake, dist is not None, world).float()
+            loss = adv_loss_gen(logits, "ce") + nerf_patch_loss(mask, data["bone_mask"][sl], gen.background_ratio)
             grads = torch.autograd.grad(loss, gen_params + [tri], allow_unused=True)       # tri: unused with the real producer
             if grads[-1] is not None:
                 tri.grad = grads[-1] if (k == 0 or tri.grad is None) else tri.grad + grads[-1]
@@ -135,14 +142,17 @@ def main():
         # ---- discriminator step (:133-147)
         dis.requires_grad_(True)
         real = data["real"]
-        loss_d = adv_loss_dis(dis(real, dist is not None, world), dis(fake, dist is not None, world), "ce")
+        with amp():
+            d_real, d_fake = dis(real, dist is not None, world).float(), dis(fake, dist is not None, world).float()
+        loss_d = adv_loss_dis(d_real, d_fake, "ce")
         sharding.accumulate_and_reduce([0], lambda _: list(torch.autograd.grad(loss_d, dis_params)), dis_params, d_red)
         dis_opt.step()
         say("discriminator step")
         m("discriminator step")
         if args.r1_every and it % args.r1_every == 0:      # :149-165
             x = real.detach().requires_grad_(True)
-            pred = dis(x, dist is not None, world)
+            with amp():
+                pred = dis(x, dist is not None, world).float()
             r1 = 0.5 * d_r1_loss(pred, x) * 16 * 0.01 + 0 * pred[0].sum()
             sharding.accumulate_and_reduce([0], lambda _: list(torch.autograd.grad(r1, dis_params)), dis_params, d_red)
             dis_opt.step()
@@ -184,7 +194,7 @@ def main():
             "config": {"workload": f"{args.size}x{args.size}, batch {args.batch} = {world} rank(s) x {args.accum} micro-batch(es) x {mb} frames, "
                                    f"Nc {args.nc} + Nf {args.nf}, tri-planes from " + ("the StyleGAN2-ADA synthesis network, " if args.producer == "stylegan" else "one learnable tri-plane per frame, ") +
                                    f"R1 on {n_r1} of {args.steps} iterations", "backend": (args.backend or "nccl") if world > 1 else None},
-            "dtype": "f32 (renderer MLP products as 3-term split fp16)", "data": "synthetic",
+            "dtype": "f32 (renderer MLP products as 3-term split fp16)" + ("; library convolutions of the 2-D networks under bf16 autocast (opt-in)" if args.amp else ""), "data": "synthetic",
             "phases_ms_mean_rank0": {k: sum(v) / len(v) for k, v in phases.items()},
             "fake_image_abs_mean": float(out.abs().mean()),
             "params_M": {"generator (renderer MLP + background network" + (" + tri-plane synthesis network)" if args.producer == "stylegan" else ")"): sum(p.numel() for p in gen_params) / 1e6,
