@@ -234,7 +234,7 @@ def test_gan_iteration_tool_runs_and_reports():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "bench_gan_step.py"), "--size", "32", "--batch", "4", "--accum", "2",
-                        "--nc", "16", "--nf", "16", "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=600)
+                        "--nc", "16", "--nf", "16", "--steps", "2", "--warmup", "1", "--producer", "planes"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["unit"] == "it/s" and line["value"] > 0 and line["n_gpus"] == 1
