@@ -140,6 +140,9 @@ __device__ __forceinline__ void tap4u(const char *__restrict__ base, unsigned la
 #ifndef ENARF_PIN
 #define ENARF_PIN 1
 #endif
+#ifndef ENARF_DIAG_HALF_LOADS
+#define ENARF_DIAG_HALF_LOADS 0
+#endif
 // an empty asm the eight values pass through: their computation can be neither sunk below nor hoisted above this point
 __device__ __forceinline__ void pin8(float v[8]) {
 #if ENARF_PIN
@@ -154,8 +157,13 @@ __device__ __forceinline__ void tap4u_issue(const char *__restrict__ base, unsig
     const f32x4 *p01 = reinterpret_cast<const f32x4 *>(base + (lane_off + ((unsigned)t.o01 << 7)));
     const f32x4 *p10 = reinterpret_cast<const f32x4 *>(base + (lane_off + ((unsigned)t.o10 << 7)));
     const f32x4 *p11 = reinterpret_cast<const f32x4 *>(base + (lane_off + ((unsigned)t.o11 << 7)));
+#if ENARF_DIAG_HALF_LOADS      // diagnosis builds only (wrong results): one 16-B load per lane and texel - what half-size texels would issue
+    r.a0 = p00[0]; r.a1 = r.a0; r.b0 = p01[0]; r.b1 = r.b0;
+    r.c0 = p10[0]; r.c1 = r.c0; r.d0 = p11[0]; r.d1 = r.d0;
+#else
     r.a0 = p00[0]; r.a1 = p00[1]; r.b0 = p01[0]; r.b1 = p01[1];
     r.c0 = p10[0]; r.c1 = p10[1]; r.d0 = p11[0]; r.d1 = p11[1];
+#endif
 }
 // Channel pairs as 2-vectors: each step is one v_pk_mul_f32 / v_pk_fma_f32 with the tap weight broadcast by op_sel
 // (16 VALU per plane). Written with vector types on purpose: from the scalar form the SLP vectoriser pairs TAPS instead
