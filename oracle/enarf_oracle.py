@@ -452,8 +452,10 @@ def render(image_coord: torch.Tensor, pose_parts: torch.Tensor, bone_length_part
            coordinate_scale: float = 3.0, Nc: int = 48, Nf: int = 64, render_scale: float = 1.0,
            bins: Optional[torch.Tensor] = None, generator: Optional[torch.Generator] = None,
            use_grid_sample: bool = False, return_taps: bool = False, multiply_density_with_weight: bool = False,
-           clamp_mask: bool = False, no_selector: bool = False):
+           clamp_mask: bool = False, no_selector: bool = False, near_far_planes=None):
     """render() (rendering.py:227-359) after transform_pose: pose_parts (B,P,4,4) unscaled.
+    `near_far_planes` = (near, far) of a LARGER batch these images were taken from (the planes are reduced over the whole
+    batch, rendering.py:15-17): lets a test restate some images of a batch without restating all of them.
 
     `bins` (B,n,Nf), sorted, replaces the random importance samples (for parity runs); rays that
     the reference would drop (B == 1 and no cube hit, rendering.py:107-110) produce zeros and their
@@ -464,7 +466,7 @@ def render(image_coord: torch.Tensor, pose_parts: torch.Tensor, bone_length_part
     pose = scale_pose_translation(pose_parts, coordinate_scale).to(dt)
     scale = canonical_scale(canonical_bone_length, bone_length_parts.to(dt), coordinate_scale)
     weights = modulated_weights(mlp, z_rend.to(dt))
-    near, far = near_far(pose)
+    near, far = near_far(pose) if near_far_planes is None else near_far_planes
     rd = ray_directions(image_coord, inv_intrinsics.to(dt))
     dmin, dmax, rvalid = frustum_range(rd, pose, near, far)
     drop = (~rvalid) if B == 1 else torch.zeros_like(rvalid)

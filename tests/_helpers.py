@@ -82,10 +82,17 @@ class Scene:
     def weights(self):
         return O.modulated_weights(self.raw["mlp"], self.raw["z_rend"])
 
-    def oracle_render(self, coord, Nc, Nf, bins, dtype=torch.float32, taps=True):
+    def oracle_render(self, coord, Nc, Nf, bins, dtype=torch.float32, taps=True, images=None):
+        """`images`: restate only these images of the batch (coord / bins already hold just them); their near / far planes are
+        the whole batch's, as in a launch over the batch (rendering.py:15-17) - the oracle's cost grows with the batch"""
         s = self.raw
-        return O.render(coord.to(dtype), self.pose_parts, self.bl_parts, s["inv_intrinsics"], self.cpose, self.cbl,
-                        s["tri_plane"], s["mlp"], s["z_rend"], self.cs, Nc, Nf, bins=bins, return_taps=taps)
+        if images is None:
+            return O.render(coord.to(dtype), self.pose_parts, self.bl_parts, s["inv_intrinsics"], self.cpose, self.cbl,
+                            s["tri_plane"], s["mlp"], s["z_rend"], self.cs, Nc, Nf, bins=bins, return_taps=taps)
+        planes = O.near_far(self.pose_scaled)
+        return O.render(coord.to(dtype), self.pose_parts[images], self.bl_parts[images], s["inv_intrinsics"][images], self.cpose,
+                        self.cbl, s["tri_plane"][images], s["mlp"], s["z_rend"][images], self.cs, Nc, Nf, bins=bins,
+                        return_taps=taps, near_far_planes=planes)
 
 
 class DeviceScene:
