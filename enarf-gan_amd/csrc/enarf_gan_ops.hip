@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void bias_act_kernel(const float *__restrict__
 // reads for 8 outputs instead of 32, everything unrolled, the taps in SGPRs. Other filter sizes and the zero-stuffing
 // up-sampler (which touches 2 x 2 taps per output) take the generic loop.
 constexpr int kUfMaxTaps = 8;                  // filter extent per axis
-constexpr int kUfTW = 64;                      // outputs per tile row; a tile is 4 * PER rows (PER vertically adjacent outputs per thread)
+constexpr int kUfLanes = 64;                   // a tile is 64 * XPT columns x 4 * PER rows of outputs (a thread: XPT columns 64 apart, PER adjacent rows)
 struct UpfirParams {
     const float *x;
     float *y;
@@ -74,11 +74,12 @@ struct UpfirParams {
 };
 __device__ __forceinline__ int floor_div(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
 
-template <int UP, int DOWN, int KH, int KW, int PER>          // KH = KW = 0: filter extents at run time
+template <int UP, int DOWN, int KH, int KW, int PER, int XPT = 1>          // KH = KW = 0: filter extents at run time
 __global__ __launch_bounds__(256) void upfirdn2d_kernel(const UpfirParams p) {
     extern __shared__ float tile[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ts = p.tstride;
-    constexpr int kUfPer = PER, kUfTH = 4 * PER;
+    constexpr int kUfPer = PER, kUfTH = 4 * PER, kUfTW = kUfLanes * XPT;
+    static_assert(XPT == 1 || (UP == 1 && KH > 0), "two columns per thread: the sliding-column form only");
     const int kh = KH ? KH : p.kh, kw = KW ? KW : p.kw;
     const int ox0 = blockIdx.x * kUfTW, oy0 = blockIdx.y * kUfTH;
     // rows / columns of x the tile can reach: u in [oy0 * DOWN, (oy0 + TH - 1) * DOWN + kh - 1], row = (u - py0) / UP
@@ -124,28 +125,32 @@ __global__ __launch_bounds__(256) void upfirdn2d_kernel(const UpfirParams p) {
         if (more) fetch(plane + gridDim.z);
         float *yp = p.y + (size_t)plane * p.OH * p.OW;
         if (UP == 1 && KH > 0) {
-            const int c0 = ox * DOWN - p.px0 - ix_min, r0 = oyb * DOWN - p.py0 - iy_min;
-            float acc[kUfPer];
+            const int r0 = oyb * DOWN - p.py0 - iy_min;
 #pragma unroll
-            for (int j = 0; j < kUfPer; ++j) acc[j] = 0.0f;
+            for (int xi = 0; xi < XPT; ++xi) {
+                const int oxx = ox + kUfLanes * xi, c0 = oxx * DOWN - p.px0 - ix_min;
+                float acc[kUfPer];
 #pragma unroll
-            for (int rr = 0; rr < (kUfPer - 1) * DOWN + KH; ++rr) {
-                float v[KW ? KW : 1];
+                for (int j = 0; j < kUfPer; ++j) acc[j] = 0.0f;
 #pragma unroll
-                for (int kx = 0; kx < KW; ++kx) v[kx] = tile[(r0 + rr) * ts + c0 + kx];
+                for (int rr = 0; rr < (kUfPer - 1) * DOWN + KH; ++rr) {
+                    float v[KW ? KW : 1];
 #pragma unroll
-                for (int j = 0; j < kUfPer; ++j) {
-                    const int ky = rr - j * DOWN;
-                    if (ky >= 0 && ky < KH) {
+                    for (int kx = 0; kx < KW; ++kx) v[kx] = tile[(r0 + rr) * ts + c0 + kx];
 #pragma unroll
-                        for (int kx = 0; kx < KW; ++kx) acc[j] = fmaf(p.kf[ky * KW + kx], v[kx], acc[j]);
+                    for (int j = 0; j < kUfPer; ++j) {
+                        const int ky = rr - j * DOWN;
+                        if (ky >= 0 && ky < KH) {
+#pragma unroll
+                            for (int kx = 0; kx < KW; ++kx) acc[j] = fmaf(p.kf[ky * KW + kx], v[kx], acc[j]);
+                        }
                     }
                 }
-            }
-            if (ox < p.OW) {
+                if (oxx < p.OW) {
 #pragma unroll
-                for (int j = 0; j < kUfPer; ++j)
-                    if (oyb + j < p.OH) yp[(size_t)(oyb + j) * p.OW + ox] = acc[j];
+                    for (int j = 0; j < kUfPer; ++j)
+                        if (oyb + j < p.OH) yp[(size_t)(oyb + j) * p.OW + oxx] = acc[j];
+                }
             }
         } else if (UP == 2 && DOWN == 1 && KH == 4 && KW == 4) {
             // the 2x up-sampler: an output sees 2 x 2 of the 4 x 4 taps (those whose zero-stuffed position holds a sample).
@@ -248,10 +253,14 @@ extern "C" int enarf_upfirdn2d(const float *x, float *out, long long planes, int
     for (int i = 0; i < kUfMaxTaps * kUfMaxTaps; ++i) p.kf[i] = 0.0f;
     for (int i = 0; i < kh; ++i)
         for (int j = 0; j < kw; ++j) p.kf[i * kw + j] = kernel_host[(kh - 1 - i) * kw + (kw - 1 - j)];
-    // 16 outputs per thread where the tile's input is small (down = 1): twice the loads in flight per wave - the kernel is bound
-    // by the bytes it keeps in flight - at 20 KB of LDS; 8 at down = 2 (39 KB)
-    const int per = down == 2 ? 8 : 16, th = 4 * per;
-    const unsigned gx = (unsigned)((OW + kUfTW - 1) / kUfTW), gy = (unsigned)((OH + th - 1) / th);
+    // The plain 4 x 4 blur takes tiles of 128 x 32 outputs (two columns per thread): with 64-column tiles every tile row of a
+    // 128-wide map touched three 128-B lines for two lines of outputs (FETCH_SIZE: 1.54x the input, profiles/r03_gan2d_traffic.json).
+    // Elsewhere 16 outputs per thread where the tile's input is small (down = 1): twice the loads in flight per wave - the
+    // kernel is bound by the bytes it keeps in flight - at 20 KB of LDS; 8 at down = 2 (39 KB).
+    const bool four = kh == 4 && kw == 4;          // the networks' [1, 3, 3, 1] filters: the unrolled sliding-column forms
+    const bool wide = four && up == 1 && down == 1 && OW > kUfLanes;
+    const int per = (down == 2 || wide) ? 8 : 16, th = 4 * per, tw = wide ? 2 * kUfLanes : kUfLanes;
+    const unsigned gx = (unsigned)((OW + tw - 1) / tw), gy = (unsigned)((OH + th - 1) / th);
     if (gy > 65535u) return host::fail(ENARF_ERR_UNSUPPORTED, "enarf_upfirdn2d: output height %d", OH);
     // planes per workgroup: enough workgroups for two rounds of 8 per CU, the rest of the planes in each one's pipeline (<= 8)
     long long ppw = planes * gx * gy / ((long long)(device_cus() > 0 ? device_cus() : 256) * 16);
@@ -259,15 +268,15 @@ extern "C" int enarf_upfirdn2d(const float *x, float *out, long long planes, int
     long long gzl = (planes + ppw - 1) / ppw;
     const unsigned gz = (unsigned)(gzl < 65535 ? gzl : 65535);
     hipStream_t st = (hipStream_t)stream;
-    // LDS tile of this configuration: the rows / columns of x that a th x 64 output tile can reach, + 1 each for an unaligned start
-    const int trows = ((th - 1) * down + kh - 1) / up + 2, tcols = ((kUfTW - 1) * down + kw - 1) / up + 2;
+    // LDS tile of this configuration: the rows / columns of x that a th x tw output tile can reach, + 1 each for an unaligned start
+    const int trows = ((th - 1) * down + kh - 1) / up + 2, tcols = ((tw - 1) * down + kw - 1) / up + 2;
     p.tstride = tcols | 1;
     const size_t lds = (size_t)trows * p.tstride * sizeof(float);
-    const bool four = kh == 4 && kw == 4;          // the networks' [1, 3, 3, 1] filters: the unrolled sliding-column form
     if (up == 2 && four) hipLaunchKernelGGL((upfirdn2d_kernel<2, 1, 4, 4, 16>), dim3(gx, gy, gz), dim3(256), lds, st, p);
     else if (up == 2) hipLaunchKernelGGL((upfirdn2d_kernel<2, 1, 0, 0, 16>), dim3(gx, gy, gz), dim3(256), lds, st, p);
     else if (down == 2 && four) hipLaunchKernelGGL((upfirdn2d_kernel<1, 2, 4, 4, 8>), dim3(gx, gy, gz), dim3(256), lds, st, p);
     else if (down == 2) hipLaunchKernelGGL((upfirdn2d_kernel<1, 2, 0, 0, 8>), dim3(gx, gy, gz), dim3(256), lds, st, p);
+    else if (wide) hipLaunchKernelGGL((upfirdn2d_kernel<1, 1, 4, 4, 8, 2>), dim3(gx, gy, gz), dim3(256), lds, st, p);
     else if (four) hipLaunchKernelGGL((upfirdn2d_kernel<1, 1, 4, 4, 16>), dim3(gx, gy, gz), dim3(256), lds, st, p);
     else hipLaunchKernelGGL((upfirdn2d_kernel<1, 1, 0, 0, 16>), dim3(gx, gy, gz), dim3(256), lds, st, p);
     return host::check_launch("enarf_upfirdn2d");
