@@ -171,7 +171,7 @@ def test_backward_c1_full_frame():
 
 def test_backward_c3_share_8_frames_per_frame_triplanes():
     """BASELINE C3's per-GPU share: 8 GAN-style frames of 128^2 rays, one tri-plane PER FRAME, in one launch."""
-    _run_case(128, 8, 48, 64, 256, per_image=24, permute=True, label="C3 share 128^2 B=8")
+    _run_case(128, 8, 48, 64, 256, per_image=24, permute=True, label="C3 share 128^2 B=8", oracle_images=[0, 3, 7])
 
 
 def test_backward_c2_forward_batch_16():

@@ -144,7 +144,7 @@ def test_gan_batches_with_per_image_triplanes_at_128(B, label):
     out = ds.render(sc.raw["image_coord"], Nc, Nf, None, seed=17, mlp_mode="f16x3", count=True, return_bins=True)
     _check_batch_properties(out, B, n, Nf)
     # oracle on a slice of EVERY image (same bins); the sub-render on those rays is bit-identical to the full launch
-    images = None if B <= 8 else list(range(0, B, 4)) + [B - 1]          # 16 frames: 5 of them restated, 32 frames: 9
+    images = None if B <= 8 else sorted({0, B // 3, 2 * B // 3, B - 1})          # larger batches: four of the frames restated
     ids, (rc, rm, rd), sub = _oracle_slices(sc, ds, out.taps["bins"], Nc, Nf, per_image=20, seed=B, images=images, mlp_mode="f16x3")
     assert float(rm.max()) > 0.5
     full_m = torch.gather(_cpu(out.mask), 1, ids)
@@ -208,7 +208,7 @@ def _to_f64(x):
     return x
 
 
-@pytest.mark.parametrize("scale", [1e-4, 1e-2, 1.0, 1e2, 1e4, 1e6])
+@pytest.mark.parametrize("scale", [1e-4, 1.0, 1e4, 1e6])
 def test_mlp_arithmetic_modes_over_feature_scales(scale):
     """`f16x3` (the default: 3-term split fp16 on MFMA) and `f32` with the FEATURE planes scaled by 1e-4 ... 1e+4 (the conv
     weights are row-normalised by the demodulation, custom_stylegan2/net.py:236-243, so their scale cancels; the feature
