@@ -67,6 +67,7 @@ struct UpfirParams {
     float *y;
     long long planes;
     int H, W, OH, OW, kh, kw, px0, py0;
+    int ex, ey;                                // EXT kernels: output columns / rows beyond the last tile column / row that it takes on as well (<= 8)
     int tstride;                               // floats per row of the LDS tile (sized by the launch for its up / down / filter:
                                                // a 4-tap blur at down = 1 needs 11 KB, not the 39 KB of the worst case - at 4
                                                // workgroups per CU the kernel was bound by the bytes it kept in flight)
@@ -74,7 +75,8 @@ struct UpfirParams {
 };
 __device__ __forceinline__ int floor_div(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
 
-template <int UP, int DOWN, int KH, int KW, int PER, int XPT = 1>          // KH = KW = 0: filter extents at run time
+constexpr int kUfExt = 8;                      // a remainder of up to 8 output columns / rows is absorbed by the last tile (EXT kernels)
+template <int UP, int DOWN, int KH, int KW, int PER, int XPT = 1, bool EXT = false>          // KH = KW = 0: filter extents at run time
 __global__ __launch_bounds__(256) void upfirdn2d_kernel(const UpfirParams p) {
     extern __shared__ float tile[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ts = p.tstride;
@@ -82,13 +84,18 @@ __global__ __launch_bounds__(256) void upfirdn2d_kernel(const UpfirParams p) {
     static_assert(XPT == 1 || (UP == 1 && KH > 0), "two columns per thread: the sliding-column form only");
     const int kh = KH ? KH : p.kh, kw = KW ? KW : p.kw;
     const int ox0 = blockIdx.x * kUfTW, oy0 = blockIdx.y * kUfTH;
+    // EXT: a 129-wide map would leave a tile column with ONE valid column, and a partly filled tile costs a full one (the kernel
+    // is bound by per-tile latency: 0.199 ms against 0.096 for 128 x 128). The last tile column / row takes the remainder on
+    // instead: a few more staged columns / rows, and a few outputs per thread computed from LDS after the tile's own.
+    const int ex = (EXT && blockIdx.x == gridDim.x - 1) ? p.ex : 0, ey = (EXT && blockIdx.y == gridDim.y - 1) ? p.ey : 0;
     // rows / columns of x the tile can reach: u in [oy0 * DOWN, (oy0 + TH - 1) * DOWN + kh - 1], row = (u - py0) / UP
-    const int iy_min = floor_div(oy0 * DOWN - p.py0 + UP - 1, UP), iy_max = floor_div((oy0 + kUfTH - 1) * DOWN + kh - 1 - p.py0, UP);
-    const int ix_min = floor_div(ox0 * DOWN - p.px0 + UP - 1, UP), ix_max = floor_div((ox0 + kUfTW - 1) * DOWN + kw - 1 - p.px0, UP);
+    const int iy_min = floor_div(oy0 * DOWN - p.py0 + UP - 1, UP), iy_max = floor_div((oy0 + kUfTH - 1 + ey) * DOWN + kh - 1 - p.py0, UP);
+    const int ix_min = floor_div(ox0 * DOWN - p.px0 + UP - 1, UP), ix_max = floor_div((ox0 + kUfTW - 1 + ex) * DOWN + kw - 1 - p.px0, UP);
     const int nr = iy_max - iy_min + 1, nc = ix_max - ix_min + 1;          // <= the launch's tile rows, tstride by construction
     const int ox = ox0 + lane, oyb = oy0 + wave * kUfPer;
     // loads per thread that cover the largest tile of this instantiation (filters up to 8 taps)
-    constexpr int MAXR = ((4 * PER - 1) * DOWN + kUfMaxTaps - 1) / UP + 1, MAXC = ((kUfTW - 1) * DOWN + kUfMaxTaps - 1) / UP + 1;
+    constexpr int XR = EXT ? kUfExt : 0;
+    constexpr int MAXR = ((4 * PER - 1 + XR) * DOWN + kUfMaxTaps - 1) / UP + 1, MAXC = ((kUfTW - 1 + XR) * DOWN + kUfMaxTaps - 1) / UP + 1;
     constexpr int NLD = (MAXR * MAXC + 255) / 256;
     const int total = nr * nc;
     const unsigned magic = (1u << 22) / (unsigned)nc + 1u;          // i / nc == (i * magic) >> 22 for i < 2^22 / nc (i < 9 400, nc <= 134)
@@ -203,6 +210,26 @@ __global__ __launch_bounds__(256) void upfirdn2d_kernel(const UpfirParams p) {
                 }
             }
         }
+        if (EXT && (ex | ey)) {          // the absorbed remainder: ex columns over all the tile's rows (+ ey), ey rows over its columns
+            const int ncol = ex * (kUfTH + ey), nrow = ey * kUfTW;
+            for (int idx = tid; idx < ncol + nrow; idx += 256) {
+                int oxx, oy;
+                if (idx < ncol) { const int q = idx / ex; oxx = ox0 + kUfTW + idx - q * ex; oy = oy0 + q; }
+                else { const int j = idx - ncol, q = j / kUfTW; oxx = ox0 + j - q * kUfTW; oy = oy0 + kUfTH + q; }
+                if (oxx < p.OW && oy < p.OH) {
+                    const int by = oy * DOWN - p.py0, bx = oxx * DOWN - p.px0;
+                    float acc = 0.0f;
+                    for (int ky = (UP == 1) ? 0 : (by & 1); ky < kh; ky += UP) {
+                        const int r = ((UP == 1) ? by + ky : (by + ky) >> 1) - iy_min;
+                        for (int kx = (UP == 1) ? 0 : (bx & 1); kx < kw; kx += UP) {
+                            const int c = ((UP == 1) ? bx + kx : (bx + kx) >> 1) - ix_min;
+                            acc = fmaf(p.kf[ky * kw + kx], tile[r * ts + c], acc);
+                        }
+                    }
+                    yp[(size_t)oy * p.OW + oxx] = acc;
+                }
+            }
+        }
         __syncthreads();          // the next plane's tile replaces this one
     }
 }
@@ -260,7 +287,13 @@ extern "C" int enarf_upfirdn2d(const float *x, float *out, long long planes, int
     const bool four = kh == 4 && kw == 4;          // the networks' [1, 3, 3, 1] filters: the unrolled sliding-column forms
     const bool wide = four && up == 1 && down == 1 && OW > kUfLanes;
     const int per = (down == 2 || wide) ? 8 : 16, th = 4 * per, tw = wide ? 2 * kUfLanes : kUfLanes;
-    const unsigned gx = (unsigned)((OW + tw - 1) / tw), gy = (unsigned)((OH + th - 1) / th);
+    // a remainder of 1..8 columns / rows beyond whole tiles goes to the last tile column / row (EXT kernels) instead of a tile of its own
+    const int rx = OW % tw, ry = OH % th;
+    // (not for the decimating form: its tile is 39 KB already and the wider staging took it to one wave per SIMD: 0.25 ms against 0.17)
+    p.ex = (four && up == 1 && down == 1 && rx > 0 && rx <= kUfExt && OW > tw) ? rx : 0;
+    p.ey = (four && up == 1 && down == 1 && ry > 0 && ry <= kUfExt && OH > th) ? ry : 0;
+    const bool ext = p.ex || p.ey;
+    const unsigned gx = (unsigned)(p.ex ? OW / tw : (OW + tw - 1) / tw), gy = (unsigned)(p.ey ? OH / th : (OH + th - 1) / th);
     if (gy > 65535u) return host::fail(ENARF_ERR_UNSUPPORTED, "enarf_upfirdn2d: output height %d", OH);
     // planes per workgroup: enough workgroups for two rounds of 8 per CU, the rest of the planes in each one's pipeline (<= 8)
     long long ppw = planes * gx * gy / ((long long)(device_cus() > 0 ? device_cus() : 256) * 16);
@@ -269,14 +302,17 @@ extern "C" int enarf_upfirdn2d(const float *x, float *out, long long planes, int
     const unsigned gz = (unsigned)(gzl < 65535 ? gzl : 65535);
     hipStream_t st = (hipStream_t)stream;
     // LDS tile of this configuration: the rows / columns of x that a th x tw output tile can reach, + 1 each for an unaligned start
-    const int trows = ((th - 1) * down + kh - 1) / up + 2, tcols = ((tw - 1) * down + kw - 1) / up + 2;
+    const int xr = ext ? kUfExt : 0;
+    const int trows = ((th - 1 + xr) * down + kh - 1) / up + 2, tcols = ((tw - 1 + xr) * down + kw - 1) / up + 2;
     p.tstride = tcols | 1;
     const size_t lds = (size_t)trows * p.tstride * sizeof(float);
     if (up == 2 && four) hipLaunchKernelGGL((upfirdn2d_kernel<2, 1, 4, 4, 16>), dim3(gx, gy, gz), dim3(256), lds, st, p);
     else if (up == 2) hipLaunchKernelGGL((upfirdn2d_kernel<2, 1, 0, 0, 16>), dim3(gx, gy, gz), dim3(256), lds, st, p);
     else if (down == 2 && four) hipLaunchKernelGGL((upfirdn2d_kernel<1, 2, 4, 4, 8>), dim3(gx, gy, gz), dim3(256), lds, st, p);
     else if (down == 2) hipLaunchKernelGGL((upfirdn2d_kernel<1, 2, 0, 0, 8>), dim3(gx, gy, gz), dim3(256), lds, st, p);
+    else if (wide && ext) hipLaunchKernelGGL((upfirdn2d_kernel<1, 1, 4, 4, 8, 2, true>), dim3(gx, gy, gz), dim3(256), lds, st, p);
     else if (wide) hipLaunchKernelGGL((upfirdn2d_kernel<1, 1, 4, 4, 8, 2>), dim3(gx, gy, gz), dim3(256), lds, st, p);
+    else if (four && ext) hipLaunchKernelGGL((upfirdn2d_kernel<1, 1, 4, 4, 16, 1, true>), dim3(gx, gy, gz), dim3(256), lds, st, p);
     else if (four) hipLaunchKernelGGL((upfirdn2d_kernel<1, 1, 4, 4, 16>), dim3(gx, gy, gz), dim3(256), lds, st, p);
     else hipLaunchKernelGGL((upfirdn2d_kernel<1, 1, 0, 0, 16>), dim3(gx, gy, gz), dim3(256), lds, st, p);
     return host::check_launch("enarf_upfirdn2d");
