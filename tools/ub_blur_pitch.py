@@ -1,5 +1,11 @@
-import sys, torch
-sys.path.insert(0, "/root/repo")
+"""Rate of the 4 x 4 blur (enarf_upfirdn2d) against the output width: is it the odd row pitch or the tile quantisation that
+costs the 129-wide case? (profiles/r03_gan2d_traffic.json: the latter.)"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from enarf_gan_amd.libraries.custom_stylegan2 import op
 dev = torch.device("cuda:0")
 k = op.make_kernel([1, 3, 3, 1]).to(dev)
